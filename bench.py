@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- K-hop GCN-normalised SpMM throughput on MI355X (BASELINE.json metric).
+
+One "step" = one K=2 propagation  Y = Â^2 X  over the whole graph (one pass of the hot path over one
+batch of synthetic input).  N=1: the Reddit-shaped configuration (BASELINE.json configs[1]:
+233k nodes, 114M edges, F=602).  N>1: the graph is 1-D row-partitioned, every rank owns a
+Reddit-shaped row block of an N-times larger graph (weak scaling) and halo feature rows are exchanged
+per hop by RCCL all-to-all over xGMI, overlapped with the interior-block SpMM.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = edges*feat/s of the whole
+job, plus `roofline` (dominant kernel, live HIP-event timing) and `cpu_baseline` (the oracle's OpenMP
+C port on a bounded sample, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="reddit", choices=["reddit", "arxiv", "products", "papers100M-shard"])
+    ap.add_argument("--hops", type=int, default=2)
+    ap.add_argument("--slices", type=int, default=int(os.environ.get("DISCO_BENCH_SLICES", "0")),
+                    help="column slices per K-hop (0 = automatic: keep each slice's X under ~190 MB)")
+    ap.add_argument("--ld-pad", type=int, default=32, help="pad the feature leading dimension to this many floats")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0)
+    ap.add_argument("--natural-order", action="store_true", help="keep natural row order (hub split only)")
+    ap.add_argument("--hub-threshold", type=int, default=0)
+    ap.add_argument("--hub-piece", type=int, default=0)
+    ap.add_argument("--skew", type=float, default=None)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; reported in config)")
+    return ap.parse_args()
+
+
+def auto_slices(n_rows_x: int, F: int) -> int:
+    """Column slices so that one slice of X (the gathered table) stays under ~190 MB, i.e. resident in
+    the 256 MiB Infinity Cache next to the streamed CSR and Y."""
+    budget = 190e6
+    s = 1
+    while n_rows_x * ((F + s - 1) // s) * 4 > budget and (F + s - 1) // s > 32:
+        s += 1
+    return s
+
+
+def b_min_bytes(nnz: int, n_rows: int, n_x_rows: int, F: int) -> float:
+    """every CSR entry read once (int32 col + f32 val), rowptr once (4 B as
+    nnz < 2^31), X read once, Y written once."""
+    return nnz * 8.0 + (n_rows + 1) * 4.0 + (n_x_rows + n_rows) * F * 4.0
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from disco_amd import SparseTensor, _lib, graphgen, ops, utils
+    lib = _lib.load()
+
+    name = "reddit" if args.workload == "papers100M-shard" and False else args.workload
+    spec = graphgen.SPECS["papers100M" if name == "papers100M-shard" else name]
+    n_local = spec.n_nodes if name != "papers100M-shard" else spec.n_nodes // 8
+    nnz_target = spec.nnz if name != "papers100M-shard" else spec.nnz // 8
+    if args.scale != 1.0:
+        n_local = int(n_local * args.scale)
+        nnz_target = int(nnz_target * args.scale * args.scale) if name == "reddit" else int(nnz_target * args.scale)
+    F, K = spec.feat, args.hops
+    skew = spec.skew if args.skew is None else args.skew
+    ld = (F + args.ld_pad - 1) // args.ld_pad * args.ld_pad
+
+    t_setup = time.time()
+    if world == 1:
+        # ---- single GPU: whole graph ---------------------------------------------------------------
+        row, col = graphgen.powerlaw_edges(n_local, nnz_target, skew, spec.seed, device=dev, symmetric=spec.symmetric)
+        adj = SparseTensor(row=row, col=col, value=None, sparse_sizes=(n_local, n_local), is_sorted=True)
+        del row, col
+        if spec.norm == "normalize_adj":
+            adj = utils.normalize_adj_csr(adj)      # utils.py:406-435 semantics, HIP kernels
+        else:
+            r, c, _ = adj.coo()                     # utils.gcn_norm(add_self_loops=False), _Sampled.py:491
+            _, w = utils.gcn_norm(torch.stack([r, c]), None, n_local, add_self_loops=False)
+            adj = adj.set_value(w)
+            del r, c
+        nnz = adj.nnz()
+        x = graphgen.features(n_local, F, spec.seed, device=dev, ld=ld)
+        y = torch.empty((n_local, ld), dtype=torch.float32, device=dev)[:, :F]
+        tmp = torch.empty((n_local, ld), dtype=torch.float32, device=dev)[:, :F]
+        n_slices = args.slices if args.slices > 0 else auto_slices(n_local, F)
+        thr = -args.hub_threshold if args.natural_order and args.hub_threshold else (-2048 if args.natural_order else args.hub_threshold)
+        ws, info = adj.schedule(thr, args.hub_piece)
+        sws_bytes = lib.disco_spmm_workspace_bytes(info, F)
+        sws = torch.empty(max(int(sws_bytes), 16), dtype=torch.uint8, device=dev)
+        per = (F + n_slices - 1) // n_slices
+        per = (per + 31) // 32 * 32
+        col_slices = [(c0, min(per, F - c0)) for c0 in range(0, F, per)]
+        stream = _lib.current_stream(dev)
+        events = []
+
+        def step(record: bool):
+            # same work as disco_khop_csr_f32, issued hop by hop so that each launch can be timed
+            for c0, f in col_slices:
+                src = x
+                for k in range(K):
+                    dst = y if k == K - 1 else tmp
+                    if record:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    _lib.check(lib.disco_spmm_csr_f32(adj._rowptr.data_ptr(), adj._col32.data_ptr(), adj._value.data_ptr(),
+                                                      n_local, src.data_ptr() + 4 * c0, src.stride(0), dst.data_ptr() + 4 * c0,
+                                                      dst.stride(0), f, 0, ws.data_ptr(), info, sws.data_ptr(), sws.numel(),
+                                                      stream), "disco_spmm_csr_f32")
+                    if record:
+                        e1.record()
+                        events.append((e0, e1, f))
+                    src = dst
+
+        units_per_step = float(K) * nnz * F
+        algo_bytes = lambda f: b_min_bytes(nnz, n_local, n_local, f)  # noqa: E731
+        parallelism = "single"
+        halo_info = None
+    else:
+        from disco_amd import dist as ddist
+        part = ddist.build_weak_scaling_partition(spec, n_local, nnz_target, skew, world, rank, dev, ld)
+        nnz = part.nnz_local
+        n_slices = 1
+        events = []
+
+        def step(record: bool):
+            part.khop(K, events if record else None)
+
+        units_per_step = float(K) * part.nnz_global * F
+        algo_bytes = lambda f: b_min_bytes(part.nnz_local, n_local, part.n_x_rows, f)  # noqa: E731
+        parallelism = f"row-partition x{world}, halo all-to-all"
+        halo_info = part.describe()
+        info = part.info_main
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (k_spmm_rows), live HIP-event timing ------------------------
+    durs_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
+    tot_bytes = sum(algo_bytes(f) for _, _, f in events)
+    avg_ms = sum(durs_ms) / max(len(durs_ms), 1)
+    achieved = tot_bytes / (sum(durs_ms) * 1e-3) / 1e9 if durs_ms else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel": "k_spmm_rows", "launches_per_step": len(events) // max(args.steps, 1),
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": round(tot_bytes / max(len(events), 1)),
+                "gather_model_GBs": round((sum((nnz * 8.0 + nnz * f * 4.0 + n_local * f * 4.0) for _, _, f in events))
+                                          / (sum(durs_ms) * 1e-3) / 1e9, 1) if durs_ms else 0.0}
+
+    value = units_per_step * args.steps / elapsed
+    out = {
+        "metric": "K-hop SpMM edges*feat/s", "value": value, "unit": "edges*feat/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{spec.name} K={K} GCN-normalised propagation, N={n_local}{'/rank' if world > 1 else ''}, "
+                               f"nnz={nnz}{'/rank' if world > 1 else ''} (incl. self-loops), F={F}",
+                   "K": K, "F": F, "nnz_per_rank": nnz, "rows_per_rank": n_local, "col_slices": n_slices, "ld": ld,
+                   "skew": skew, "parallelism": parallelism, "scale": args.scale,
+                   "schedule": {"hub_rows": int(info.n_hub_rows), "hub_pieces": int(info.n_hub_pieces),
+                                "max_row_nnz": int(info.max_row_nnz)},
+                   "setup_s": round(t_setup, 1)},
+        "roofline": roofline,
+    }
+    if halo_info:
+        out["config"]["halo"] = halo_info
+
+    # ---- CPU baseline: the oracle's OpenMP C port on a bounded sample (rank 0, N=1 only) --------------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle
+        rows = args.cpu_sample_rows or max(256, min(n_local, int(1.0e10 / max(1.0, nnz / n_local * F))))
+        rows = min(rows, n_local)
+        rp = adj._rowptr[: rows + 1].cpu().numpy()
+        e_end = int(rp[-1])
+        cs = adj._col32[:e_end].cpu().numpy().astype("int64")
+        vs = adj._value[:e_end].cpu().numpy()
+        xh = x.cpu().numpy()
+        c_oracle.spmm_csr_f32(rp[:65], cs, vs, xh)  # touch / warm
+        tc = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            c_oracle.spmm_csr_f32(rp, cs, vs, xh, "sum")
+        tc = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": e_end * F * reps / tc, "unit": "edges*feat/s", "cores": c_oracle.num_threads(),
+                               "kind": "port",
+                               "sample": f"rows [0,{rows}) of the same normalised CSR ({e_end} entries), {reps} SpMM passes at F={F}, "
+                                         f"oracle/spmm_ref.c (OpenMP), {tc:.1f} s"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,44 @@
+// Internal declarations shared by the translation units of libdisco_hip.so.
+#ifndef DISCO_INTERNAL_H
+#define DISCO_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/disco_hip.h"
+
+namespace disco {
+
+struct Tuning {
+  int force_g = 0;    // 0 = automatic
+  int force_nv = 0;   // 0 = automatic
+  int max_vec = 0;    // 0 = 4
+};
+
+Tuning& tuning();
+void set_last_hip_error(int e);
+
+#define DISCO_HIP_TRY(expr)                                    \
+  do {                                                         \
+    hipError_t e__ = (expr);                                   \
+    if (e__ != hipSuccess) {                                   \
+      ::disco::set_last_hip_error((int)e__);                   \
+      return DISCO_EHIP;                                       \
+    }                                                          \
+  } while (0)
+
+#define DISCO_CHECK_LAUNCH()                                   \
+  do {                                                         \
+    hipError_t e__ = hipGetLastError();                        \
+    if (e__ != hipSuccess) {                                   \
+      ::disco::set_last_hip_error((int)e__);                   \
+      return DISCO_EHIP;                                       \
+    }                                                          \
+  } while (0)
+
+}  // namespace disco
+
+// Not part of the public header: tuning knobs for benchmarks ("force_g", "force_nv", "max_vec").
+extern "C" int disco_set_tuning(const char* key, int64_t value);
+
+#endif

@@ -1,0 +1,196 @@
+// disco_norm.hip -- GCN normalisation kernels (gfx950) and the library's small utilities.
+//
+// A3 semantics: /root/reference/utils.py:406-435 (normalize_adj; float64, row degree) + :634 (one
+//               rounding to float32).
+// A1 semantics: /root/reference/utils.py:242-247 (gcn_norm edge-index branch; float32, degree by
+//               column, left-to-right product).  Same code at models/convs_large/gcn_conv.py:65-70.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "disco_internal.h"
+
+namespace disco {
+
+static thread_local int g_last_hip_error = 0;
+void set_last_hip_error(int e) { g_last_hip_error = e; }
+Tuning& tuning() { static Tuning t; return t; }
+
+// ---- CSR row sums in float64: 16 lanes per row, fixed-order tree ---------------------------------
+__global__ __launch_bounds__(256) void k_csr_rowsum_f64(const int64_t* __restrict__ rowptr, const float* __restrict__ val,
+                                                        int64_t n_rows, int add_identity, double* __restrict__ out) {
+  const int gl = threadIdx.x & 15;
+  int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  double s = 0.0;
+  int64_t b = 0, e = 0;
+  if (row < n_rows) { b = rowptr[row]; e = rowptr[row + 1]; }
+  if (val) {
+    for (int64_t i = b + gl; i < e; i += 16) s += (double)val[i];
+  } else {
+    s = 0.0;
+  }
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+  if (!val) s = (double)(e - b);
+  if (add_identity) s += 1.0;  // mx + I (utils.py:426): every row sum grows by one
+  if (row < n_rows && gl == 0) out[row] = s;
+}
+
+__global__ __launch_bounds__(256) void k_inv_sqrt_f64(double* __restrict__ d, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double v = d[i];
+  // numpy: np.power(rowsum, -1/2); inf -> 0 (utils.py:428-429).  A negative sum gives NaN there too.
+  double r = 1.0 / sqrt(v);
+  if (isinf(r)) r = 0.0;
+  d[i] = r;
+}
+
+__global__ __launch_bounds__(256) void k_gcn_scale_csr(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       const float* __restrict__ vin, int64_t n_rows, int add_identity,
+                                                       const double* __restrict__ r, float* __restrict__ vout) {
+  const int gl = threadIdx.x & 15;
+  int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  if (row >= n_rows) return;
+  const int64_t b = rowptr[row], e = rowptr[row + 1];
+  const double rr = r[row];
+  for (int64_t i = b + gl; i < e; i += 16) {
+    double v = vin ? (double)vin[i] : 1.0;
+    const int64_t c = col[i];
+    if (add_identity && c == row) v += 1.0;  // the diagonal entry of mx + I, in float64 like scipy
+    vout[i] = (float)((rr * v) * r[c]);
+  }
+}
+
+// ---- edge-index branch ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_degree_count(const int64_t* __restrict__ idx, int64_t E, unsigned int* __restrict__ cnt) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < E) atomicAdd(&cnt[idx[i]], 1u);  // integer counts: exact and order independent
+}
+
+__global__ __launch_bounds__(256) void k_u32_to_f32(float* __restrict__ d, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) d[i] = (float)__float_as_uint(d[i]);
+}
+
+__global__ __launch_bounds__(256) void k_degree_ordered(const int64_t* __restrict__ segptr, const int64_t* __restrict__ order,
+                                                        const float* __restrict__ w, int64_t N, float* __restrict__ deg) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float s = 0.0f;
+  for (int64_t k = segptr[i]; k < segptr[i + 1]; ++k) s += w[order[k]];  // serial float32, edge order
+  deg[i] = s;
+}
+
+__global__ __launch_bounds__(256) void k_inv_sqrt_f32(float* __restrict__ d, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float r = 1.0f / sqrtf(d[i]);  // two correctly rounded ops == torch CPU pow_(-0.5)
+  if (isinf(r)) r = 0.0f;
+  d[i] = r;
+}
+
+__global__ __launch_bounds__(256) void k_gcn_coo_apply(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                                                       const float* __restrict__ w, int64_t E, const float* __restrict__ dis,
+                                                       float* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= E) return;
+  float wi = w ? w[i] : 1.0f;
+  out[i] = __fmul_rn(__fmul_rn(dis[row[i]], wi), dis[col[i]]);
+}
+
+static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace disco
+
+using namespace disco;
+
+extern "C" int disco_abi_version(void) { return DISCO_ABI_VERSION; }
+extern "C" int disco_last_hip_error(void) { return g_last_hip_error; }
+
+extern "C" const char* disco_status_string(int status) {
+  switch (status) {
+    case DISCO_OK: return "ok";
+    case DISCO_EINVAL: return "invalid argument";
+    case DISCO_EUNSUPPORTED: return "unsupported shape";
+    case DISCO_EWORKSPACE: return "workspace too small";
+    case DISCO_EHIP: return "HIP runtime error";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int disco_set_tuning(const char* key, int64_t value) {
+  if (!key) return DISCO_EINVAL;
+  Tuning& t = tuning();
+  if (!strcmp(key, "force_g")) t.force_g = (int)value;
+  else if (!strcmp(key, "force_nv")) t.force_nv = (int)value;
+  else if (!strcmp(key, "max_vec")) t.max_vec = (int)value;
+  else return DISCO_EINVAL;
+  return DISCO_OK;
+}
+
+extern "C" int disco_csr_rowsum_f64(const int64_t* rowptr, const float* val, int64_t n_rows, int add_identity,
+                                    double* rowsum, void* stream) {
+  if (n_rows < 0) return DISCO_EINVAL;
+  if (n_rows == 0) return DISCO_OK;
+  if (!rowptr || !rowsum) return DISCO_EINVAL;
+  hipLaunchKernelGGL(k_csr_rowsum_f64, dim3(blocks_for(n_rows, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr,
+                     val, n_rows, add_identity, rowsum);
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}
+
+extern "C" int disco_gcn_norm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val_in, int64_t n_rows,
+                                      int add_identity, double* rowsum, float* val_out, void* stream) {
+  if (n_rows < 0) return DISCO_EINVAL;
+  if (n_rows == 0) return DISCO_OK;
+  if (!rowptr || !col || !rowsum || !val_out) return DISCO_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_inv_sqrt_f64, dim3(blocks_for(n_rows, 256)), dim3(256), 0, s, rowsum, n_rows);
+  hipLaunchKernelGGL(k_gcn_scale_csr, dim3(blocks_for(n_rows, 16)), dim3(256), 0, s, rowptr, col, val_in, n_rows,
+                     add_identity, (const double*)rowsum, val_out);
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}
+
+extern "C" int disco_degree_count_f32(const int64_t* idx, int64_t E, int64_t N, float* deg, void* stream) {
+  if (E < 0 || N < 0) return DISCO_EINVAL;
+  if (N == 0) return DISCO_OK;
+  if (!deg || (E > 0 && !idx)) return DISCO_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISCO_HIP_TRY(hipMemsetAsync(deg, 0, sizeof(float) * (size_t)N, s));
+  if (E > 0) hipLaunchKernelGGL(k_degree_count, dim3(blocks_for(E, 256)), dim3(256), 0, s, idx, E, reinterpret_cast<unsigned int*>(deg));
+  hipLaunchKernelGGL(k_u32_to_f32, dim3(blocks_for(N, 256)), dim3(256), 0, s, deg, N);
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}
+
+extern "C" int disco_degree_ordered_f32(const int64_t* segptr, const int64_t* order, const float* w, int64_t N, float* deg,
+                                        void* stream) {
+  if (N < 0) return DISCO_EINVAL;
+  if (N == 0) return DISCO_OK;
+  if (!segptr || !order || !w || !deg) return DISCO_EINVAL;
+  hipLaunchKernelGGL(k_degree_ordered, dim3(blocks_for(N, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), segptr, order,
+                     w, N, deg);
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}
+
+extern "C" int disco_inv_sqrt_f32(float* deg, int64_t N, void* stream) {
+  if (N < 0) return DISCO_EINVAL;
+  if (N == 0) return DISCO_OK;
+  if (!deg) return DISCO_EINVAL;
+  hipLaunchKernelGGL(k_inv_sqrt_f32, dim3(blocks_for(N, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), deg, N);
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}
+
+extern "C" int disco_gcn_norm_coo_apply_f32(const int64_t* row, const int64_t* col, const float* w_in, int64_t E,
+                                            const float* dis, float* w_out, void* stream) {
+  if (E < 0) return DISCO_EINVAL;
+  if (E == 0) return DISCO_OK;
+  if (!row || !col || !dis || !w_out) return DISCO_EINVAL;
+  hipLaunchKernelGGL(k_gcn_coo_apply, dim3(blocks_for(E, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), row, col, w_in,
+                     E, dis, w_out);
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}

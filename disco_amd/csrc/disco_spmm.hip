@@ -1,0 +1,455 @@
+// disco_spmm.hip -- CSR row-parallel SpMM (sum / mean / max) for gfx950 (MI355X, CDNA4).
+//
+// Replaces torch_sparse.matmul reached from
+//   /root/reference/models/convs_large/sg_conv.py:92-93, gcn_conv.py:170-171,
+//   sage_conv.py:148-150, gin_conv.py:88-90
+// and MessagePassing(aggr="max").propagate at /root/reference/LargeScaleCondensing.py:152-172.
+//
+// Design:
+//   * a GROUP of G lanes (16/32/64) owns one output row; each lane owns NV vectors of VEC floats
+//     of that row, so a row gather is NV coalesced 4*VEC*G-byte wave loads and the sum lives in
+//     registers (no atomics, CSR order => deterministic);
+//   * (col,val) are fetched G entries at a time by one coalesced load and broadcast inside the
+//     group (v_readlane -> SGPR addressing when G == 64, ds_bpermute otherwise);
+//   * U neighbour rows are in flight per group (U*NV independent 16-byte loads per lane);
+//   * rows come in degree-binned order (heaviest first); rows above the hub threshold are cut
+//     into pieces, each piece summed by the 8 waves of a workgroup through LDS, and pieces of
+//     one row are combined in piece order by a fix-up kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "disco_internal.h"
+
+namespace disco {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int VEC> struct Vec;
+template <> struct Vec<1> { typedef float type; };
+template <> struct Vec<2> { typedef f2 type; };
+template <> struct Vec<4> { typedef f4 type; };
+
+#ifndef DISCO_U1
+#define DISCO_U1 8
+#endif
+#ifndef DISCO_U2
+#define DISCO_U2 4
+#endif
+#ifndef DISCO_U3
+#define DISCO_U3 4
+#endif
+#ifndef DISCO_U45
+#define DISCO_U45 2
+#endif
+
+template <int NV> struct Unroll { static constexpr int value = NV == 1 ? DISCO_U1 : NV == 2 ? DISCO_U2 : NV == 3 ? DISCO_U3 : DISCO_U45; };
+
+constexpr int OP_SUM = 0;
+constexpr int OP_MAX = 1;
+constexpr int FLAG_MEAN = 1;
+constexpr int FLAG_ACCUM = 2;
+
+template <int G> __device__ __forceinline__ int bcast_i(int v, int j) {
+  if constexpr (G == 64) {
+    return __builtin_amdgcn_readlane(v, j);
+  } else {
+    return __shfl(v, j, G);
+  }
+}
+template <int G> __device__ __forceinline__ float bcast_f(float v, int j) {
+  return __int_as_float(bcast_i<G>(__float_as_int(v), j));
+}
+
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL));
+  int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+template <int VEC, int OP> __device__ __forceinline__ void vinit(typename Vec<VEC>::type& a) {
+  if constexpr (OP == OP_SUM) a = 0.0f; else a = -INFINITY;
+}
+
+template <int VEC, int OP, bool HASVAL>
+__device__ __forceinline__ void vupdate(typename Vec<VEC>::type& a, float w, const typename Vec<VEC>::type& x) {
+  if constexpr (VEC == 1) {
+    if constexpr (OP == OP_SUM) a = HASVAL ? fmaf(w, x, a) : a + x;
+    else a = fmaxf(a, HASVAL ? w * x : x);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      if constexpr (OP == OP_SUM) a[i] = HASVAL ? fmaf(w, x[i], a[i]) : a[i] + x[i];
+      else a[i] = fmaxf(a[i], HASVAL ? w * x[i] : x[i]);
+    }
+  }
+}
+
+template <int VEC, int OP> __device__ __forceinline__ void vcombine(typename Vec<VEC>::type& a, const typename Vec<VEC>::type& b) {
+  if constexpr (VEC == 1) {
+    if constexpr (OP == OP_SUM) a = a + b; else a = fmaxf(a, b);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      if constexpr (OP == OP_SUM) a[i] = a[i] + b[i]; else a[i] = fmaxf(a[i], b[i]);
+    }
+  }
+}
+
+// Accumulate entries [beg, end) of one CSR row into acc[NV].  All lanes of the group call this
+// with the same (beg, end); lane `gl` owns vectors gl + G*v.
+template <int VEC, int G, int NV, int OP, bool HASVAL>
+__device__ __forceinline__ void accumulate_range(int64_t beg, int64_t end, const int32_t* __restrict__ col,
+                                                 const float* __restrict__ val, const float* __restrict__ x,
+                                                 int64_t ldx, int nvec, int gl,
+                                                 typename Vec<VEC>::type (&acc)[NV]) {
+  typedef typename Vec<VEC>::type V;
+  constexpr int U = Unroll<NV>::value;
+  // Lanes past the row's last vector re-read the last valid vector (no branch in the load
+  // stream); their accumulators are never stored.
+  int64_t off[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    int idx = gl + G * v;
+    idx = idx < nvec ? idx : nvec - 1;
+    off[v] = (int64_t)idx * VEC;
+  }
+  for (int64_t base = beg; base < end; base += G) {
+    int64_t rem = end - base;
+    int n = rem < G ? (int)rem : G;
+    int cv = 0;
+    float wv = 0.0f;
+    if (gl < n) {
+      cv = col[base + gl];
+      if constexpr (HASVAL) wv = val[base + gl];
+    }
+    int j = 0;
+    for (; j + U <= n; j += U) {
+      V xr[U][NV];
+      float w[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int c = bcast_i<G>(cv, j + u);
+        w[u] = HASVAL ? bcast_f<G>(wv, j + u) : 1.0f;
+        const float* rp = x + (int64_t)c * ldx;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) xr[u][v] = *reinterpret_cast<const V*>(rp + off[v]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) vupdate<VEC, OP, HASVAL>(acc[v], w[u], xr[u][v]);
+      }
+    }
+    for (; j < n; ++j) {
+      int c = bcast_i<G>(cv, j);
+      float w = HASVAL ? bcast_f<G>(wv, j) : 1.0f;
+      const float* rp = x + (int64_t)c * ldx;
+      V xr[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) xr[v] = *reinterpret_cast<const V*>(rp + off[v]);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) vupdate<VEC, OP, HASVAL>(acc[v], w, xr[v]);
+    }
+  }
+}
+
+template <int VEC> __device__ __forceinline__ typename Vec<VEC>::type vdiv(typename Vec<VEC>::type a, float d) {
+  if constexpr (VEC == 1) return a / d;
+  else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) a[i] = a[i] / d;
+    return a;
+  }
+}
+
+// ---- rows below the hub threshold: one group of G lanes per row ---------------------------------
+template <int VEC, int G, int NV, int OP, bool HASVAL>
+__global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                   const float* __restrict__ val, const float* __restrict__ x,
+                                                   int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
+                                                   const uint32_t* __restrict__ perm, int64_t first, int64_t count,
+                                                   int flags) {
+  typedef typename Vec<VEC>::type V;
+  constexpr int RPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int gl = lane % G;
+  int64_t grp = ((int64_t)blockIdx.x * 4 + wave) * RPW + lane / G;
+  if (grp >= count) return;
+  int64_t row = perm ? (int64_t)perm[first + grp] : first + grp;
+  int64_t beg = rowptr[row], end = rowptr[row + 1];
+  if constexpr (G == 64) {
+    row = uniform64(row);
+    beg = uniform64(beg);
+    end = uniform64(end);
+  }
+  V acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) vinit<VEC, OP>(acc[v]);
+  accumulate_range<VEC, G, NV, OP, HASVAL>(beg, end, col, val, x, ldx, nvec, gl, acc);
+  const bool empty = end == beg;
+  const float cnt = (float)(end - beg);
+  const bool mean = flags & FLAG_MEAN, accum = flags & FLAG_ACCUM;
+  float* yr = y + row * ldy;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    int idx = gl + G * v;
+    if (idx < nvec) {
+      V a = acc[v];
+      V* dst = reinterpret_cast<V*>(yr + (int64_t)idx * VEC);
+      if constexpr (OP == OP_MAX) { if (empty) a = 0.0f; }
+      else {
+        if (mean && !empty) a = vdiv<VEC>(a, cnt);
+        if (accum) a = *dst + a;  // y += A x: the earlier (interior) part first, then this part
+      }
+      *dst = a;
+    }
+  }
+}
+
+// ---- hub rows: one 512-thread workgroup per piece, partial sums staged in LDS ----------------------
+template <int VEC, int G, int NV, int OP, bool HASVAL>
+__global__ __launch_bounds__(512) void k_spmm_hub(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                  const float* __restrict__ val, const float* __restrict__ x,
+                                                  int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
+                                                  const int32_t* __restrict__ piece_row,
+                                                  const int64_t* __restrict__ piece_begin,
+                                                  const int64_t* __restrict__ piece_end,
+                                                  const int32_t* __restrict__ piece_slot, float* __restrict__ partial,
+                                                  int64_t ldp, int flags) {
+  typedef typename Vec<VEC>::type V;
+  constexpr int NG = 512 / G;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  V* ldsv = reinterpret_cast<V*>(lds);
+  const int p = blockIdx.x;
+  const int64_t pb = piece_begin[p], pe = piece_end[p];
+  const int64_t row = piece_row[p];
+  const int slot = piece_slot[p];
+  const int g = threadIdx.x / G, gl = threadIdx.x % G;
+  const int64_t len = pe - pb;
+  int64_t chunk = (len + NG - 1) / NG;
+  chunk = (chunk + G - 1) / G * G;  // whole cooperative (col,val) fetches per group
+  int64_t b = pb + (int64_t)g * chunk;
+  b = b < pe ? b : pe;
+  int64_t e = b + chunk;
+  e = e < pe ? e : pe;
+  if constexpr (G == 64) { b = uniform64(b); e = uniform64(e); }
+  V acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) vinit<VEC, OP>(acc[v]);
+  accumulate_range<VEC, G, NV, OP, HASVAL>(b, e, col, val, x, ldx, nvec, gl, acc);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    int idx = gl + G * v;
+    if (idx < nvec) ldsv[(int64_t)g * nvec + idx] = acc[v];
+  }
+  __syncthreads();
+  float* dst = slot < 0 ? y + row * ldy : partial + (int64_t)slot * ldp;
+  const float cnt = (float)(rowptr[row + 1] - rowptr[row]);
+  for (int i = threadIdx.x; i < nvec; i += 512) {
+    V s = ldsv[i];
+#pragma unroll 4
+    for (int k = 1; k < NG; ++k) vcombine<VEC, OP>(s, ldsv[(int64_t)k * nvec + i]);
+    V* out = reinterpret_cast<V*>(dst + (int64_t)i * VEC);
+    if constexpr (OP == OP_SUM) {
+      if ((flags & FLAG_MEAN) && slot < 0) s = vdiv<VEC>(s, cnt);
+      if ((flags & FLAG_ACCUM) && slot < 0) s = *out + s;
+    }
+    *out = s;
+  }
+}
+
+// ---- hub rows cut into several pieces: add the pieces' partial rows in piece order ------------------
+template <int OP>
+__global__ __launch_bounds__(256) void k_hub_combine(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ multi_row,
+                                                     const int64_t* __restrict__ multi_first, const float* __restrict__ partial,
+                                                     int64_t ldp, float* __restrict__ y, int64_t ldy, int64_t F, int flags) {
+  const int m = blockIdx.x;
+  const int64_t row = multi_row[m];
+  const int64_t s0 = multi_first[m], s1 = multi_first[m + 1];
+  const float cnt = (float)(rowptr[row + 1] - rowptr[row]);
+  for (int64_t c = threadIdx.x; c < F; c += 256) {
+    float s = partial[s0 * ldp + c];
+    for (int64_t k = s0 + 1; k < s1; ++k) {
+      float t = partial[k * ldp + c];
+      if constexpr (OP == OP_SUM) s = s + t; else s = fmaxf(s, t);
+    }
+    if constexpr (OP == OP_SUM) {
+      if (flags & FLAG_MEAN) s = s / cnt;
+      if (flags & FLAG_ACCUM) s = y[row * ldy + c] + s;
+    }
+    y[row * ldy + c] = s;
+  }
+}
+
+// ---- host-side dispatch -----------------------------------------------------------------------------
+struct SpmmArgs {
+  const int64_t* rowptr; const int32_t* col; const float* val; int64_t n_rows;
+  const float* x; int64_t ldx; float* y; int64_t ldy; int64_t F; int reduce;
+  const char* sched; const disco_schedule_info* info; float* partial; int64_t ldp; hipStream_t stream;
+};
+
+template <int VEC, int G, int NV, int OP, bool HASVAL>
+static int launch_cfg(const SpmmArgs& a, int nvec) {
+  const int mean = (a.reduce == DISCO_REDUCE_MEAN ? FLAG_MEAN : 0) | (a.reduce == DISCO_REDUCE_SUM_ACC ? FLAG_ACCUM : 0);
+  constexpr int RPW = 64 / G;
+  const uint32_t* perm = nullptr;
+  int64_t first = 0, count = a.n_rows;
+  if (a.info) {
+    const disco_schedule_info& s = *a.info;
+    perm = reinterpret_cast<const uint32_t*>(a.sched + s.off_perm);
+    first = s.n_hub_rows;
+    count = s.n_rows - s.n_hub_rows;
+    if (s.n_hub_pieces > 0) {
+      size_t lds_bytes = (size_t)(512 / G) * nvec * VEC * sizeof(float);
+      hipLaunchKernelGGL((k_spmm_hub<VEC, G, NV, OP, HASVAL>), dim3((unsigned)s.n_hub_pieces), dim3(512), lds_bytes, a.stream,
+                         a.rowptr, a.col, a.val, a.x, a.ldx, a.y, a.ldy, nvec,
+                         reinterpret_cast<const int32_t*>(a.sched + s.off_piece_row),
+                         reinterpret_cast<const int64_t*>(a.sched + s.off_piece_begin),
+                         reinterpret_cast<const int64_t*>(a.sched + s.off_piece_end),
+                         reinterpret_cast<const int32_t*>(a.sched + s.off_piece_slot), a.partial, a.ldp, mean);
+      if (s.n_multi_rows > 0) {
+        hipLaunchKernelGGL((k_hub_combine<OP>), dim3((unsigned)s.n_multi_rows), dim3(256), 0, a.stream, a.rowptr,
+                           reinterpret_cast<const int32_t*>(a.sched + s.off_multi_row),
+                           reinterpret_cast<const int64_t*>(a.sched + s.off_multi_first), a.partial, a.ldp, a.y, a.ldy,
+                           a.F, mean);
+      }
+    }
+  }
+  if (count > 0) {
+    int64_t blocks = (count + 4 * RPW - 1) / (4 * RPW);
+    if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
+    hipLaunchKernelGGL((k_spmm_rows<VEC, G, NV, OP, HASVAL>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
+                       a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, mean);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_last_hip_error((int)e); return DISCO_EHIP; }
+  return DISCO_OK;
+}
+
+template <int VEC, int G, int NV>
+static int launch_op(const SpmmArgs& a, int nvec) {
+  const bool hv = a.val != nullptr;
+  if (a.reduce == DISCO_REDUCE_MAX)
+    return hv ? launch_cfg<VEC, G, NV, OP_MAX, true>(a, nvec) : launch_cfg<VEC, G, NV, OP_MAX, false>(a, nvec);
+  return hv ? launch_cfg<VEC, G, NV, OP_SUM, true>(a, nvec) : launch_cfg<VEC, G, NV, OP_SUM, false>(a, nvec);
+}
+
+template <int VEC>
+static int launch_vec(const SpmmArgs& a, int nvec) {
+  const Tuning& t = tuning();
+  int G, NV;
+  if (t.force_g > 0 && t.force_nv > 0 && (int64_t)t.force_g * t.force_nv >= nvec) { G = t.force_g; NV = t.force_nv; }
+  else if (nvec <= 16) { G = 16; NV = 1; }
+  else if (nvec <= 32) { G = 32; NV = 1; }
+  else { G = 64; NV = (nvec + 63) / 64; }
+  if (G == 16 && NV == 1) return launch_op<VEC, 16, 1>(a, nvec);
+  if (G == 16 && NV == 2) return launch_op<VEC, 16, 2>(a, nvec);
+  if (G == 32 && NV == 1) return launch_op<VEC, 32, 1>(a, nvec);
+  if (G == 32 && NV == 2) return launch_op<VEC, 32, 2>(a, nvec);
+  if (G == 64 && NV == 1) return launch_op<VEC, 64, 1>(a, nvec);
+  if (G == 64 && NV == 2) return launch_op<VEC, 64, 2>(a, nvec);
+  if (G == 64 && NV == 3) return launch_op<VEC, 64, 3>(a, nvec);
+  if (G == 64 && NV == 4) return launch_op<VEC, 64, 4>(a, nvec);
+  if (G == 64 && NV == 5) return launch_op<VEC, 64, 5>(a, nvec);
+  return DISCO_EUNSUPPORTED;
+}
+
+static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Widest vector the operands allow: the leading dimensions and base addresses must keep every
+// row VEC-aligned, and a partial last vector must stay inside the row's leading dimension.
+static int pick_vec(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* partial, int64_t ldp, int64_t F) {
+  const Tuning& t = tuning();
+  for (int vec = (t.max_vec > 0 ? t.max_vec : 4); vec >= 2; vec >>= 1) {
+    int64_t fr = (F + vec - 1) / vec * vec;
+    if (ldx % vec || ldy % vec || ldx < fr || ldy < fr) continue;
+    if (!aligned_to(x, 4 * vec) || !aligned_to(y, 4 * vec)) continue;
+    if (partial && (ldp % vec || ldp < fr || !aligned_to(partial, 4 * vec))) continue;
+    return vec;
+  }
+  return 1;
+}
+
+int spmm_dispatch(const SpmmArgs& a0) {
+  SpmmArgs a = a0;
+  // Columns are processed in blocks of at most 5*64 vectors (one pass for F <= 1280 at VEC=4).
+  int vec = pick_vec(a.x, a.ldx, a.y, a.ldy, a.partial, a.ldp, a.F);
+  const int64_t max_cols = (int64_t)5 * 64 * vec;
+  for (int64_t c0 = 0; c0 < a0.F; c0 += max_cols) {
+    int64_t f = a0.F - c0 < max_cols ? a0.F - c0 : max_cols;
+    a.x = a0.x + c0; a.y = a0.y + c0; a.F = f;
+    a.partial = a0.partial;  // partial rows are reused per column block (stream order serialises)
+    int nvec = (int)((f + vec - 1) / vec);
+    int rc;
+    if (vec == 4) rc = launch_vec<4>(a, nvec);
+    else if (vec == 2) rc = launch_vec<2>(a, nvec);
+    else rc = launch_vec<1>(a, nvec);
+    if (rc != DISCO_OK) return rc;
+  }
+  return DISCO_OK;
+}
+
+}  // namespace disco
+
+using namespace disco;
+
+extern "C" size_t disco_spmm_workspace_bytes(const disco_schedule_info* info, int64_t F) {
+  if (!info || info->n_hub_partials <= 0 || F <= 0) return 0;
+  int64_t ldp = (F + 3) / 4 * 4;
+  return (size_t)info->n_hub_partials * (size_t)ldp * sizeof(float);
+}
+
+extern "C" int disco_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                                  const float* x, int64_t ldx, float* y, int64_t ldy, int64_t F, int reduce,
+                                  const void* sched_ws, const disco_schedule_info* info, void* spmm_ws,
+                                  size_t spmm_ws_bytes, void* stream) {
+  if (n_rows < 0 || F < 0 || reduce < 0 || reduce > 3) return DISCO_EINVAL;
+  if (n_rows == 0 || F == 0) return DISCO_OK;
+  if (!rowptr || !x || !y || ldx < F || ldy < F) return DISCO_EINVAL;
+  if (x == y) return DISCO_EINVAL;
+  if (info && (!sched_ws || info->n_rows != n_rows)) return DISCO_EINVAL;
+  SpmmArgs a;
+  a.rowptr = rowptr; a.col = col; a.val = val; a.n_rows = n_rows; a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy;
+  a.F = F; a.reduce = reduce; a.sched = static_cast<const char*>(sched_ws); a.info = info;
+  a.partial = nullptr; a.ldp = 0; a.stream = static_cast<hipStream_t>(stream);
+  if (info && info->n_hub_partials > 0) {
+    size_t need = disco_spmm_workspace_bytes(info, F);
+    if (!spmm_ws || spmm_ws_bytes < need) return DISCO_EWORKSPACE;
+    if (!aligned_to(spmm_ws, 16)) return DISCO_EINVAL;
+    a.partial = static_cast<float*>(spmm_ws);
+    a.ldp = (F + 3) / 4 * 4;
+  }
+  if (info && info->nnz > 0 && !col) return DISCO_EINVAL;
+  return spmm_dispatch(a);
+}
+
+extern "C" int disco_khop_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n, int K,
+                                  const float* x, int64_t ldx, float* y, int64_t ldy, float* tmp0, float* tmp1,
+                                  int64_t ldt, int64_t F, int n_col_slices, const void* sched_ws,
+                                  const disco_schedule_info* info, void* spmm_ws, size_t spmm_ws_bytes, void* stream) {
+  if (K < 1 || n < 0 || F < 0) return DISCO_EINVAL;
+  if (n == 0 || F == 0) return DISCO_OK;
+  if (K >= 2 && (!tmp0 || ldt < F)) return DISCO_EINVAL;
+  if (K >= 3 && !tmp1) return DISCO_EINVAL;
+  if (n_col_slices < 1) n_col_slices = 1;
+  // Slice boundaries are multiples of 32 floats (128 B) so every slice keeps the operands' alignment.
+  int64_t per = (F + n_col_slices - 1) / n_col_slices;
+  per = (per + 31) / 32 * 32;
+  for (int64_t c0 = 0; c0 < F; c0 += per) {
+    int64_t f = F - c0 < per ? F - c0 : per;
+    const float* src = x + c0;
+    int64_t lds = ldx;
+    for (int k = 0; k < K; ++k) {
+      float* dst; int64_t ldd;
+      if (k == K - 1) { dst = y + c0; ldd = ldy; }
+      else { dst = ((k & 1) ? tmp1 : tmp0) + c0; ldd = ldt; }
+      int rc = disco_spmm_csr_f32(rowptr, col, val, n, src, lds, dst, ldd, f, DISCO_REDUCE_SUM, sched_ws, info,
+                                  spmm_ws, spmm_ws_bytes, stream);
+      if (rc != DISCO_OK) return rc;
+      src = dst; lds = ldd;
+    }
+  }
+  return DISCO_OK;
+}

@@ -1,0 +1,157 @@
+"""Python entry points of the propagation path: thin wrappers that check operands, fetch the
+current HIP stream and call the C ABI (include/disco_hip.h).  No CPU fallback exists.
+
+spmm       <- torch_sparse.matmul(adj_t, x, reduce)      sg_conv.py:92-93, gcn_conv.py:170-171
+khop       <- for k in range(K): x = propagate(adj_t, x)  sg_conv.py:74-77
+max_aggregate <- MessagePassing(aggr="max").propagate     LargeScaleCondensing.py:152-172
+(paths relative to /root/reference)
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .sparse import SparseTensor
+
+_REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2, "sum_acc": 3}
+
+
+def _as_operand(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype != torch.float32:
+        raise TypeError(f"disco_amd propagates float32 features, got {x.dtype}")
+    if x.dim() != 2:
+        raise ValueError("features must be [N, F]")
+    if x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+        x = x.contiguous()
+    return x
+
+
+def _require_cuda(adj: SparseTensor, x: torch.Tensor) -> None:
+    if adj.device.type != "cuda" or x.device.type != "cuda":
+        raise RuntimeError("disco_amd runs on the GPU only (adjacency on %s, features on %s); there is no CPU "
+                           "fallback" % (adj.device, x.device))
+    if adj.device != x.device:
+        raise RuntimeError(f"adjacency on {adj.device} but features on {x.device}")
+
+
+def _padded_empty(n: int, F: int, device, pad: int = 4) -> torch.Tensor:
+    """[n, F] view of a buffer whose leading dimension is a multiple of `pad` floats (16-byte rows)."""
+    ld = (F + pad - 1) // pad * pad
+    return torch.empty((n, ld), dtype=torch.float32, device=device)[:, :F]
+
+
+def spmm_raw(adj: SparseTensor, x: torch.Tensor, reduce: str = "sum", out: Optional[torch.Tensor] = None,
+             use_schedule: bool = True) -> torch.Tensor:
+    """y = reduce_e val[e] * x[col[e]] through disco_spmm_csr_f32 (no autograd)."""
+    x = _as_operand(x)
+    _require_cuda(adj, x)
+    n, m = adj.sparse_sizes()
+    if x.shape[0] < m:
+        raise ValueError(f"adjacency has {m} columns but x has {x.shape[0]} rows")
+    F = x.shape[1]
+    if out is None:
+        out = _padded_empty(n, F, x.device)
+    lib = _lib.load()
+    val = adj._value
+    if val is not None and val.dtype != torch.float32:
+        val = val.to(torch.float32)
+    with torch.cuda.device(x.device):
+        stream = _lib.current_stream(x.device)
+        ws_ptr, info_ref, sws, sws_bytes = None, None, None, 0
+        if use_schedule and n > 0:
+            ws, info = adj.schedule()
+            ws_ptr, info_ref = _lib.ptr(ws), info
+            need = lib.disco_spmm_workspace_bytes(info, F)
+            if need:
+                sws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+                sws_bytes = sws.numel()
+        _lib.check(lib.disco_spmm_csr_f32(_lib.ptr(adj._rowptr), _lib.ptr(adj._col32), _lib.ptr(val), n,
+                                          _lib.ptr(x), x.stride(0), _lib.ptr(out), out.stride(0), F, _REDUCE[reduce],
+                                          ws_ptr, info_ref, _lib.ptr(sws), sws_bytes, stream), "disco_spmm_csr_f32")
+    return out
+
+
+class _SpmmFn(torch.autograd.Function):
+    """Autograd for reduce in {sum, mean}: dX = A^T dY (gradient to x only, as in the reference where
+    edge weights are detached, /root/reference/LargeScaleCondensing.py:309-310)."""
+
+    @staticmethod
+    def forward(ctx, x, adj, reduce):
+        ctx.adj, ctx.reduce = adj, reduce
+        ctx.x_rows = x.shape[0]
+        return spmm_raw(adj, x, reduce)
+
+    @staticmethod
+    def backward(ctx, gy):
+        adj, reduce = ctx.adj, ctx.reduce
+        gy = gy.contiguous()
+        if reduce == "mean":
+            cnt = (adj._rowptr[1:] - adj._rowptr[:-1]).clamp(min=1).to(gy.dtype)
+            gy = gy / cnt[:, None]
+        gx = spmm_raw(adj.t(), gy, "sum")
+        if gx.shape[0] < ctx.x_rows:
+            gx = torch.cat([gx, gx.new_zeros(ctx.x_rows - gx.shape[0], gx.shape[1])])
+        return gx, None, None
+
+
+def spmm(adj: SparseTensor, x: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
+    """``matmul(adj_t, x, reduce)``; differentiable w.r.t. x for sum/mean."""
+    reduce = "sum" if reduce == "add" else reduce
+    if reduce not in ("sum", "mean", "max"):
+        raise ValueError(f"unsupported reduce {reduce!r}")
+    if x.requires_grad and torch.is_grad_enabled():
+        if reduce == "max":
+            raise NotImplementedError("reduce='max' is forward-only on this path")
+        return _SpmmFn.apply(x, adj, reduce)
+    return spmm_raw(adj, x, reduce)
+
+
+matmul = spmm
+
+
+def khop(adj: SparseTensor, x: torch.Tensor, K: int, n_col_slices: int = 1, out: Optional[torch.Tensor] = None,
+         scratch: Optional[torch.Tensor] = None, use_schedule: bool = True) -> torch.Tensor:
+    """y = A^K x through disco_khop_csr_f32 (forward only; use repeated spmm() under autograd).
+
+    `scratch` may be a caller-owned float32 buffer of at least ``min(K-1, 2) * n * ld`` elements."""
+    x = _as_operand(x)
+    _require_cuda(adj, x)
+    n, m = adj.sparse_sizes()
+    if n != m or x.shape[0] != n:
+        raise ValueError("khop needs a square adjacency matching x")
+    F = x.shape[1]
+    if out is None:
+        out = _padded_empty(n, F, x.device)
+    ldt = (F + 31) // 32 * 32
+    ntmp = min(K - 1, 2)
+    need = ntmp * n * ldt
+    if scratch is None or scratch.numel() < need:
+        scratch = torch.empty(max(need, 1), dtype=torch.float32, device=x.device)
+    t0 = scratch[: n * ldt] if ntmp >= 1 else None
+    t1 = scratch[n * ldt: 2 * n * ldt] if ntmp >= 2 else None
+    lib = _lib.load()
+    val = adj._value
+    with torch.cuda.device(x.device):
+        stream = _lib.current_stream(x.device)
+        ws_ptr, info_ref, sws, sws_bytes = None, None, None, 0
+        if use_schedule and n > 0:
+            ws, info = adj.schedule()
+            ws_ptr, info_ref = _lib.ptr(ws), info
+            nb = lib.disco_spmm_workspace_bytes(info, F)
+            if nb:
+                sws = torch.empty(int(nb), dtype=torch.uint8, device=x.device)
+                sws_bytes = sws.numel()
+        _lib.check(lib.disco_khop_csr_f32(_lib.ptr(adj._rowptr), _lib.ptr(adj._col32), _lib.ptr(val), n, K,
+                                          _lib.ptr(x), x.stride(0), _lib.ptr(out), out.stride(0), _lib.ptr(t0),
+                                          _lib.ptr(t1), ldt, F, n_col_slices, ws_ptr, info_ref, _lib.ptr(sws),
+                                          sws_bytes, stream), "disco_khop_csr_f32")
+    return out
+
+
+def max_aggregate(adj: SparseTensor, x: torch.Tensor) -> torch.Tensor:
+    """T[i] = max over the entries of CSR row i of x[col]; values ignored; empty rows give 0."""
+    if adj.has_value():
+        adj = adj.set_value(None)
+    return spmm_raw(adj, x, "max")

@@ -1,0 +1,213 @@
+"""CSR adjacency container with the subset of ``torch_sparse.SparseTensor`` the reference uses.
+
+The reference hands ``SparseTensor(row=, col=, value=, sparse_sizes=).t()`` to its convolutions
+(/root/reference/LargeScaleCondensing.py:153,486-488) and touches ``.to()``, ``.cuda()``,
+``.cpu()``, ``.t()``, ``.storage.row()/col()/rowptr()/value()``, ``.csr()``, ``.coo()``,
+``.size()``, ``.sparse_sizes()``, ``.nnz()``.  torch_sparse is not available on MI355X boxes, so
+this class provides that surface and owns what the HIP kernels need: int64 ``rowptr``, int32
+``col``, float32 ``value`` on the device, plus the lazily built degree-binned schedule and the
+transposed structure used by backward.
+
+Index bookkeeping (sort, cumsum, bincount) is done with stock torch ops: it is layout plumbing,
+not the accelerated path.  All arithmetic on the path goes through libdisco_hip.so.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+class _Storage:
+    """``adj.storage`` facade: ``row()``, ``col()``, ``rowptr()``, ``value()``."""
+
+    def __init__(self, owner: "SparseTensor"):
+        self._o = owner
+
+    def row(self) -> torch.Tensor:
+        return self._o._row()
+
+    def col(self) -> torch.Tensor:
+        return self._o._col64()
+
+    def rowptr(self) -> torch.Tensor:
+        return self._o._rowptr
+
+    def value(self) -> Optional[torch.Tensor]:
+        return self._o._value
+
+    def sparse_sizes(self) -> Tuple[int, int]:
+        return self._o._sizes
+
+
+class SparseTensor:
+    def __init__(self, row: Optional[torch.Tensor] = None, rowptr: Optional[torch.Tensor] = None,
+                 col: Optional[torch.Tensor] = None, value: Optional[torch.Tensor] = None,
+                 sparse_sizes: Optional[Tuple[int, int]] = None, is_sorted: bool = False):
+        assert col is not None and (row is not None or rowptr is not None)
+        device = col.device
+        if sparse_sizes is None:
+            m = int(row.max()) + 1 if row is not None and row.numel() else (rowptr.numel() - 1 if rowptr is not None else 0)
+            n = int(col.max()) + 1 if col.numel() else 0
+            sparse_sizes = (m, n)
+        sparse_sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
+        if rowptr is None:
+            row = row.to(torch.int64)
+            col = col.to(torch.int64)
+            if not is_sorted and row.numel():
+                # row-major order, duplicates kept -- torch_sparse.SparseTensor construction
+                key = row * sparse_sizes[1] + col
+                perm = torch.argsort(key, stable=True)
+                row, col = row[perm], col[perm]
+                if value is not None:
+                    value = value[perm]
+            counts = torch.bincount(row, minlength=sparse_sizes[0])
+            rowptr = torch.zeros(sparse_sizes[0] + 1, dtype=torch.int64, device=device)
+            torch.cumsum(counts, 0, out=rowptr[1:])
+        if col.numel() and (int(col.max()) >= sparse_sizes[1] or int(col.min()) < 0):
+            raise ValueError("column index outside sparse_sizes")  # the kernels trust col[] (checked once here)
+        if rowptr.numel() != sparse_sizes[0] + 1 or int(rowptr[-1]) != col.numel():
+            raise ValueError("rowptr inconsistent with col / sparse_sizes")
+        self._rowptr = rowptr.to(torch.int64).contiguous()
+        self._col32 = col.to(torch.int32).contiguous()
+        self._value = None if value is None else value.contiguous()
+        self._sizes = sparse_sizes
+        self._sched = None          # (ws tensor, ScheduleInfo)
+        self._sched_key = None
+        self._t: Optional["SparseTensor"] = None
+        self.storage = _Storage(self)
+
+    # ---- constructors ---------------------------------------------------------------------
+    @classmethod
+    def from_edge_index(cls, edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor] = None,
+                        sparse_sizes: Optional[Tuple[int, int]] = None, is_sorted: bool = False) -> "SparseTensor":
+        return cls(row=edge_index[0], col=edge_index[1], value=edge_attr, sparse_sizes=sparse_sizes, is_sorted=is_sorted)
+
+    @classmethod
+    def from_torch_sparse_coo_tensor(cls, mat: torch.Tensor, has_value: bool = True) -> "SparseTensor":
+        mat = mat.coalesce()
+        idx = mat.indices()
+        return cls(row=idx[0], col=idx[1], value=mat.values() if has_value else None,
+                   sparse_sizes=tuple(mat.shape[:2]), is_sorted=True)
+
+    @classmethod
+    def from_torch_sparse_csr_tensor(cls, mat: torch.Tensor, has_value: bool = True) -> "SparseTensor":
+        return cls(rowptr=mat.crow_indices(), col=mat.col_indices(), value=mat.values() if has_value else None,
+                   sparse_sizes=tuple(mat.shape[:2]), is_sorted=True)
+
+    @classmethod
+    def from_scipy(cls, mat, has_value: bool = True) -> "SparseTensor":
+        mat = mat.tocsr()
+        mat.sort_indices()
+        return cls(rowptr=torch.from_numpy(mat.indptr.astype("int64")), col=torch.from_numpy(mat.indices.astype("int64")),
+                   value=torch.from_numpy(mat.data.astype("float32")) if has_value else None,
+                   sparse_sizes=mat.shape, is_sorted=True)
+
+    # ---- accessors --------------------------------------------------------------------------
+    @property
+    def device(self) -> torch.device:
+        return self._col32.device
+
+    def _row(self) -> torch.Tensor:
+        n = self._sizes[0]
+        return torch.repeat_interleave(torch.arange(n, device=self.device), self._rowptr[1:] - self._rowptr[:-1])
+
+    def _col64(self) -> torch.Tensor:
+        return self._col32.to(torch.int64)
+
+    def csr(self):
+        return self._rowptr, self._col64(), self._value
+
+    def coo(self):
+        return self._row(), self._col64(), self._value
+
+    def size(self, dim: int) -> int:
+        return self._sizes[dim]
+
+    def sizes(self):
+        return list(self._sizes)
+
+    def sparse_sizes(self) -> Tuple[int, int]:
+        return self._sizes
+
+    def sparse_size(self, dim: int) -> int:
+        return self._sizes[dim]
+
+    def nnz(self) -> int:
+        return self._col32.numel()
+
+    def has_value(self) -> bool:
+        return self._value is not None
+
+    def set_value(self, value: Optional[torch.Tensor], layout: Optional[str] = None) -> "SparseTensor":
+        out = SparseTensor(rowptr=self._rowptr, col=self._col32, value=value, sparse_sizes=self._sizes, is_sorted=True)
+        out._sched, out._sched_key = self._sched, self._sched_key
+        return out
+
+    def fill_value(self, fill: float, dtype=torch.float32) -> "SparseTensor":
+        return self.set_value(torch.full((self.nnz(),), fill, dtype=dtype, device=self.device))
+
+    def to_torch_sparse_coo_tensor(self) -> torch.Tensor:
+        row, col, val = self.coo()
+        if val is None:
+            val = torch.ones(self.nnz(), device=self.device)
+        return torch.sparse_coo_tensor(torch.stack([row, col]), val, self._sizes)
+
+    def to_dense(self) -> torch.Tensor:
+        return self.to_torch_sparse_coo_tensor().to_dense()
+
+    # ---- movement -----------------------------------------------------------------------------
+    def to(self, device, non_blocking: bool = False) -> "SparseTensor":
+        device = torch.device(device) if not isinstance(device, torch.device) else device
+        if device == self.device or (device.type == "cuda" and device.index is None and self.device.type == "cuda"):
+            return self
+        out = SparseTensor(rowptr=self._rowptr.to(device, non_blocking=non_blocking),
+                           col=self._col32.to(device, non_blocking=non_blocking),
+                           value=None if self._value is None else self._value.to(device, non_blocking=non_blocking),
+                           sparse_sizes=self._sizes, is_sorted=True)
+        return out
+
+    def cuda(self) -> "SparseTensor":
+        return self.to(torch.device("cuda", torch.cuda.current_device()))
+
+    def cpu(self) -> "SparseTensor":
+        return self.to(torch.device("cpu"))
+
+    # ---- transpose ------------------------------------------------------------------------------
+    def t(self) -> "SparseTensor":
+        """Transposed matrix as CSR (row-major sorted, stable in the original entry order)."""
+        if self._t is None:
+            row = self._row()
+            col = self._col64()
+            out = SparseTensor(row=col, col=row, value=self._value, sparse_sizes=(self._sizes[1], self._sizes[0]))
+            out._t = self
+            self._t = out
+        return self._t
+
+    # ---- device-side schedule -------------------------------------------------------------------
+    def schedule(self, hub_threshold: int = 0, hub_piece: int = 0):
+        """Degree-binned schedule (device workspace + host info), built once per structure."""
+        key = (hub_threshold, hub_piece)
+        if self._sched is None or self._sched_key != key:
+            assert self.device.type == "cuda", "schedules live on the GPU"
+            lib = _lib.load()
+            n, nnz = self._sizes[0], self.nnz()
+            with torch.cuda.device(self.device):
+                nbytes = lib.disco_schedule_workspace_bytes(n, nnz, hub_threshold, hub_piece)
+                ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+                info = _lib.ScheduleInfo()
+                _lib.check(lib.disco_schedule_build(_lib.ptr(self._rowptr), n, nnz, hub_threshold, hub_piece,
+                                                    _lib.ptr(ws), ws.numel(), info, _lib.current_stream(self.device)),
+                           "disco_schedule_build")
+                # keep only the part the SpMM kernels read
+                keep = int(info.off_multi_first + 8 * (info.n_multi_rows + 2))
+                keep = min(max(keep, 256), ws.numel())
+                if keep < ws.numel() // 2:
+                    ws = ws[:keep].clone()
+            self._sched, self._sched_key = (ws, info), key
+        return self._sched
+
+    def __repr__(self) -> str:
+        return f"SparseTensor(sizes={self._sizes}, nnz={self.nnz()}, has_value={self.has_value()}, device={self.device})"

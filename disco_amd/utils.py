@@ -1,0 +1,202 @@
+"""Adjacency normalisation with the reference's function names and semantics
+(/root/reference/utils.py), computed by the HIP kernels of libdisco_hip.so.
+
+Only the normalisation block of the reference's ``utils.py`` is on the hot path (SURVEY.md
+section 2 row 3); data loading, metrics and the nettack helpers are out of scope.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+import torch
+
+from . import _lib
+from .sparse import SparseTensor
+
+
+def is_sparse_tensor(tensor) -> bool:
+    """/root/reference/utils.py:662-679."""
+    return isinstance(tensor, torch.Tensor) and tensor.layout == torch.sparse_coo
+
+
+def maybe_num_nodes(edge_index: torch.Tensor, num_nodes: Optional[int] = None) -> int:
+    if num_nodes is not None:
+        return int(num_nodes)
+    return int(edge_index.max()) + 1 if edge_index.numel() else 0
+
+
+def add_self_loops(edge_index, edge_weight=None, fill_value=1, num_nodes=None):
+    """/root/reference/utils.py:457-471: append one loop per node (no de-duplication)."""
+    loop_index = torch.arange(0, num_nodes, dtype=torch.long, device=edge_index.device)
+    loop_index = loop_index.unsqueeze(0).repeat(2, 1)
+    if edge_weight is not None:
+        assert edge_weight.numel() == edge_index.size(1)
+        loop_weight = edge_weight.new_full((num_nodes,), fill_value)
+        edge_weight = torch.cat([edge_weight, loop_weight], dim=0)
+    edge_index = torch.cat([edge_index, loop_index], dim=1)
+    return edge_index, edge_weight
+
+
+def add_remaining_self_loops(edge_index, edge_weight, fill_value, num_nodes):
+    """torch_geometric 2.1.0 semantics (called at /root/reference/utils.py:237): keep non-loop
+    edges, append one loop per node, existing loop weights win over ``fill_value``."""
+    row, col = edge_index[0], edge_index[1]
+    mask = row != col
+    loop_w = edge_weight.new_full((num_nodes,), fill_value)
+    inv = ~mask
+    loop_w[row[inv]] = edge_weight[inv]
+    loops = torch.arange(num_nodes, dtype=edge_index.dtype, device=edge_index.device)
+    ei = torch.cat([edge_index[:, mask], torch.stack([loops, loops])], dim=1)
+    ew = torch.cat([edge_weight[mask], loop_w])
+    return ei, ew
+
+
+def _require_cuda(t: torch.Tensor, what: str) -> None:
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{what}: tensors must live on the GPU (got {t.device}); disco_amd has no CPU fallback")
+
+
+def gcn_norm(edge_index: Union[torch.Tensor, SparseTensor], edge_weight: Optional[torch.Tensor] = None,
+             num_nodes: Optional[int] = None, improved: bool = False, add_self_loops: bool = True,
+             flow: str = "source_to_target", dtype=None):
+    """/root/reference/utils.py:209-247 (copy at models/convs_large/gcn_conv.py:32-70).
+
+    Tensor branch (:228-247): ``deg = scatter_add(w, col)`` (by COLUMN for source_to_target),
+    ``dis = deg^-1/2`` with inf -> 0, returns ``(edge_index, dis[row] * w * dis[col])``.
+      * edge_weight None: integer degree counts (exact, any order);
+      * weighted: the degree is summed per node in original edge order in float32, i.e. the
+        result of the reference's serial CPU scatter_add, bit for bit.
+    SparseTensor branch (:214-226): fill_value(1) if no values, optional unit diagonal, ROW degree.
+    """
+    fill_value = 2.0 if improved else 1.0
+    lib = _lib.load()
+    if isinstance(edge_index, SparseTensor):
+        assert flow in ["source_to_target"]
+        adj_t = edge_index
+        _require_cuda(adj_t._col32, "gcn_norm")
+        if add_self_loops:
+            adj_t = fill_diag(adj_t, fill_value)
+        # float32 semantics of torch_sparse.sum / mul are restated through the float64 row-sum
+        # kernel (exact for the unit-weight graphs the dead branch would see), then scaled.
+        n = adj_t.size(0)
+        with torch.cuda.device(adj_t.device):
+            s = _lib.current_stream(adj_t.device)
+            rs = torch.empty(n, dtype=torch.float64, device=adj_t.device)
+            val = adj_t._value
+            _lib.check(lib.disco_csr_rowsum_f64(_lib.ptr(adj_t._rowptr), _lib.ptr(val), n, 0, _lib.ptr(rs), s), "disco_csr_rowsum_f64")
+            out = torch.empty(adj_t.nnz(), dtype=torch.float32, device=adj_t.device)
+            _lib.check(lib.disco_gcn_norm_csr_f32(_lib.ptr(adj_t._rowptr), _lib.ptr(adj_t._col32), _lib.ptr(val), n, 0,
+                                                  _lib.ptr(rs), _lib.ptr(out), s), "disco_gcn_norm_csr_f32")
+        return adj_t.set_value(out)
+
+    assert flow in ["source_to_target", "target_to_source"]
+    _require_cuda(edge_index, "gcn_norm")
+    num_nodes = maybe_num_nodes(edge_index, num_nodes)
+    if add_self_loops:
+        if edge_weight is None:
+            edge_weight = torch.ones((edge_index.size(1),), dtype=dtype or torch.float32, device=edge_index.device)
+        edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, fill_value, num_nodes)
+    edge_index = edge_index.contiguous()
+    row, col = edge_index[0], edge_index[1]
+    idx = col if flow == "source_to_target" else row
+    E = edge_index.size(1)
+    dev = edge_index.device
+    with torch.cuda.device(dev):
+        s = _lib.current_stream(dev)
+        deg = torch.empty(num_nodes, dtype=torch.float32, device=dev)
+        if edge_weight is None:
+            _lib.check(lib.disco_degree_count_f32(_lib.ptr(idx), E, num_nodes, _lib.ptr(deg), s), "disco_degree_count_f32")
+            w = None
+        else:
+            w = edge_weight.to(torch.float32).contiguous()
+            order = torch.argsort(idx, stable=True)
+            segptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(torch.bincount(idx, minlength=num_nodes), 0, out=segptr[1:])
+            _lib.check(lib.disco_degree_ordered_f32(_lib.ptr(segptr), _lib.ptr(order), _lib.ptr(w), num_nodes,
+                                                    _lib.ptr(deg), s), "disco_degree_ordered_f32")
+        _lib.check(lib.disco_inv_sqrt_f32(_lib.ptr(deg), num_nodes, s), "disco_inv_sqrt_f32")
+        out = torch.empty(E, dtype=torch.float32, device=dev)
+        _lib.check(lib.disco_gcn_norm_coo_apply_f32(_lib.ptr(row), _lib.ptr(col), _lib.ptr(w), E, _lib.ptr(deg),
+                                                    _lib.ptr(out), s), "disco_gcn_norm_coo_apply_f32")
+    return edge_index, out
+
+
+def fill_diag(adj: SparseTensor, fill_value: float) -> SparseTensor:
+    """torch_sparse.fill_diag [upstream, restated]: set the whole diagonal to ``fill_value``
+    (existing diagonal entries are replaced).  Used only by the dead SparseTensor branch of
+    gcn_norm (/root/reference/utils.py:219-220)."""
+    row, col, val = adj.coo()
+    n = min(adj.sparse_sizes())
+    if val is None:
+        val = torch.ones(adj.nnz(), dtype=torch.float32, device=adj.device)
+    keep = row != col
+    d = torch.arange(n, device=adj.device)
+    return SparseTensor(row=torch.cat([row[keep], d]), col=torch.cat([col[keep], d]),
+                        value=torch.cat([val[keep], val.new_full((n,), fill_value)]), sparse_sizes=adj.sparse_sizes())
+
+
+def normalize_adj_csr(adj: SparseTensor) -> SparseTensor:
+    """Core of ``normalize_adj`` (/root/reference/utils.py:406-435) on a CSR whose duplicates are
+    already summed: ``if mx[0,0] == 0: mx += I``; r = rowsum^-1/2 (inf -> 0) in float64;
+    val = float32(r[row] * val * r[col])."""
+    _require_cuda(adj._col32, "normalize_adj")
+    n = adj.size(0)
+    row, col, val = adj.coo()
+    if val is None:
+        val = torch.ones(adj.nnz(), dtype=torch.float32, device=adj.device)
+    has00 = bool(((row == 0) & (col == 0) & (val != 0)).any()) if n > 0 else True
+    add_identity = 0 if has00 else 1
+    if add_identity:
+        # Structure of mx + I: a zero-valued diagonal entry is merged into every row (x + 0 is exact in
+        # float32); the kernels add the 1 in float64, as scipy's `mx + sp.eye(n)` does.
+        d = torch.arange(n, device=adj.device)
+        m = torch.sparse_coo_tensor(torch.stack([torch.cat([row, d]), torch.cat([col, d])]),
+                                    torch.cat([val.to(torch.float32), torch.zeros(n, dtype=torch.float32, device=adj.device)]),
+                                    adj.sparse_sizes()).coalesce()
+        adj = SparseTensor(row=m.indices()[0], col=m.indices()[1], value=m.values(),
+                           sparse_sizes=adj.sparse_sizes(), is_sorted=True)
+    lib = _lib.load()
+    with torch.cuda.device(adj.device):
+        s = _lib.current_stream(adj.device)
+        rs = torch.empty(n, dtype=torch.float64, device=adj.device)
+        _lib.check(lib.disco_csr_rowsum_f64(_lib.ptr(adj._rowptr), _lib.ptr(adj._value), n, add_identity, _lib.ptr(rs), s),
+                   "disco_csr_rowsum_f64")
+        out = torch.empty(adj.nnz(), dtype=torch.float32, device=adj.device)
+        _lib.check(lib.disco_gcn_norm_csr_f32(_lib.ptr(adj._rowptr), _lib.ptr(adj._col32), _lib.ptr(adj._value), n,
+                                              add_identity, _lib.ptr(rs), _lib.ptr(out), s), "disco_gcn_norm_csr_f32")
+    return adj.set_value(out)
+
+
+def normalize_adj_tensor(adj: torch.Tensor, sparse: bool = False):
+    """/root/reference/utils.py:473-494.
+
+    sparse=True : adj is a torch sparse COO tensor; duplicates are summed (``to_scipy`` ->
+                  ``csr_matrix``, :651-656), then normalize_adj (:406-435); returns a torch sparse
+                  COO float32 tensor on adj's device like the reference (:484).
+    sparse=False: dense ``D^-1/2 (A + I) D^-1/2`` in float32 with stock torch ops (:486-493) --
+                  a small dense matrix product, not part of the accelerated path.
+    """
+    if sparse:
+        _require_cuda(adj, "normalize_adj_tensor")
+        st = SparseTensor.from_torch_sparse_coo_tensor(adj)
+        out = normalize_adj_csr(st)
+        row, col, val = out.coo()
+        return torch.sparse_coo_tensor(torch.stack([row, col]), val, adj.shape).coalesce()
+    device = adj.device
+    mx = adj + torch.eye(adj.shape[0]).to(device)
+    rowsum = mx.sum(1)
+    r_inv = rowsum.pow(-1 / 2).flatten()
+    r_inv[torch.isinf(r_inv)] = 0.
+    r_mat_inv = torch.diag(r_inv)
+    mx = r_mat_inv @ mx
+    mx = mx @ r_mat_inv
+    return mx
+
+
+def to_adj_t(adj) -> SparseTensor:
+    """``SparseTensor(row=adj._indices()[0], col=adj._indices()[1], value=adj._values(),
+    sparse_sizes=adj.size()).t()`` (/root/reference/LargeScaleCondensing.py:486)."""
+    if isinstance(adj, SparseTensor):
+        return adj.t()
+    return SparseTensor(row=adj._indices()[0], col=adj._indices()[1], value=adj._values(),
+                        sparse_sizes=tuple(adj.size())).t()

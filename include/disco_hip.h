@@ -1,0 +1,146 @@
+/*
+ * disco_hip.h -- C ABI of libdisco_hip.so, the MI355X (gfx950) implementation of DisCo's
+ * GCN-normalised sparse propagation hot path.
+ *
+ * The reference (BangHonor/DisCo) is pure Python and has no FFI of its own: the arithmetic of
+ * this path lives in torch_sparse / torch_scatter / torch_geometric wheels.  Each entry point
+ * below therefore cites the *reference call site* whose third-party kernel it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued
+ *     on it and nothing here synchronises, except disco_schedule_build (documented there);
+ *   - no entry point allocates or frees device memory: callers pass outputs and a workspace
+ *     whose size they query first;
+ *   - return value: 0 = ok, <0 = error (see disco_status_string); no exceptions cross the ABI;
+ *   - CSR: rowptr int64[n_rows+1], col int32[nnz], val float32[nnz] (val may be NULL = all 1);
+ *   - dense operands are row-major float32 with an explicit leading dimension in elements.
+ */
+#ifndef DISCO_HIP_H
+#define DISCO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DISCO_ABI_VERSION 1
+
+enum disco_status {
+  DISCO_OK = 0,
+  DISCO_EINVAL = -1,       /* bad argument (null pointer, negative size, misaligned ld) */
+  DISCO_EUNSUPPORTED = -2, /* shape outside what the kernels are instantiated for */
+  DISCO_EWORKSPACE = -3,   /* workspace too small */
+  DISCO_EHIP = -4          /* a HIP runtime call failed; see disco_last_hip_error() */
+};
+
+enum disco_reduce {
+  DISCO_REDUCE_SUM = 0,
+  DISCO_REDUCE_MEAN = 1,
+  DISCO_REDUCE_MAX = 2,
+  DISCO_REDUCE_SUM_ACC = 3 /* y += A x: used for the halo block of a row-partitioned graph */
+};
+
+/* Host-side description of a degree-binned schedule living in a device workspace. */
+typedef struct disco_schedule_info {
+  int64_t n_rows;
+  int64_t nnz;
+  int64_t hub_threshold;   /* rows with more entries than this go to the hub kernel */
+  int64_t hub_piece;       /* max entries one hub workgroup handles */
+  int64_t n_hub_rows;
+  int64_t n_hub_pieces;
+  int64_t n_hub_partials;  /* pieces that write a partial row (hub rows with >1 piece) */
+  int64_t n_multi_rows;    /* hub rows with >1 piece (combined by the fix-up kernel) */
+  int64_t max_row_nnz;
+  /* byte offsets into the schedule workspace */
+  int64_t off_perm, off_piece_row, off_piece_begin, off_piece_end, off_piece_slot;
+  int64_t off_multi_row, off_multi_first;
+  int64_t ws_bytes;
+} disco_schedule_info;
+
+int disco_abi_version(void);
+const char* disco_status_string(int status);
+int disco_last_hip_error(void);
+
+/* ---- schedule -------------------------------------------------------------------------
+ * Degree-binned row schedule for a CSR structure (north_star: "one wavefront (or
+ * sub-wavefront) per row chosen by a degree-binned schedule ... LDS staging of hub-node rows").
+ * No counterpart in the reference: torch_sparse's spmm launches one warp per row in natural
+ * order (/root/reference/models/convs_large/sg_conv.py:92-93 -> torch_sparse.matmul).
+ * disco_schedule_build SYNCHRONISES `stream` once (it reads three counters back) -- call it
+ * once per graph, outside any capture.  hub_threshold/hub_piece <= 0 select the defaults. */
+size_t disco_schedule_workspace_bytes(int64_t n_rows, int64_t nnz, int64_t hub_threshold,
+                                      int64_t hub_piece);
+int disco_schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz,
+                         int64_t hub_threshold, int64_t hub_piece, void* sched_ws,
+                         size_t sched_ws_bytes, disco_schedule_info* info_host, void* stream);
+
+/* ---- SpMM -------------------------------------------------------------------------------
+ * y[r, 0:F] = reduce_{e in row r} val[e] * x[col[e], 0:F]
+ * Replaces torch_sparse.matmul(adj_t, x, reduce) reached from
+ *   /root/reference/models/convs_large/sg_conv.py:92-93   (SGConv.message_and_aggregate)
+ *   /root/reference/models/convs_large/gcn_conv.py:170-171 (GCNConv.message_and_aggregate)
+ *   /root/reference/models/convs_large/sage_conv.py:148-150, gin_conv.py:88-90 (reduce=mean)
+ * and, with reduce=MAX and val=NULL, MessagePassing(aggr="max").propagate at
+ *   /root/reference/LargeScaleCondensing.py:152-153,172 (rows without entries give 0).
+ * `sched_ws`/`info` may be NULL: rows are then walked in natural order and no row is split.
+ * x rows are addressed by col[], so x needs >= max(col)+1 rows; x and y must not alias.
+ * Deterministic: no atomics; per row the entries are accumulated in CSR order (hub rows: per
+ * group in CSR order, groups and pieces combined in a fixed order). */
+size_t disco_spmm_workspace_bytes(const disco_schedule_info* info_host, int64_t F);
+int disco_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val,
+                       int64_t n_rows, const float* x, int64_t ldx, float* y, int64_t ldy,
+                       int64_t F, int reduce, const void* sched_ws,
+                       const disco_schedule_info* info_host, void* spmm_ws, size_t spmm_ws_bytes,
+                       void* stream);
+
+/* ---- K-hop propagation ------------------------------------------------------------------
+ * y = A^K x for a square CSR A: `for k in range(K): x = propagate(adj_t, x=x)`
+ * (/root/reference/models/convs_large/sg_conv.py:74-77).  tmp0/tmp1 are caller-owned
+ * [n_rows, ldt] ping-pong buffers (tmp0 needed for K>=2, tmp1 for K>=3).
+ * n_col_slices >= 1 runs the K hops independently on column slices of x (each slice's
+ * working set then fits the 256 MiB Infinity Cache); results are identical for any value. */
+int disco_khop_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n,
+                       int K, const float* x, int64_t ldx, float* y, int64_t ldy, float* tmp0,
+                       float* tmp1, int64_t ldt, int64_t F, int n_col_slices,
+                       const void* sched_ws, const disco_schedule_info* info_host, void* spmm_ws,
+                       size_t spmm_ws_bytes, void* stream);
+
+/* ---- normalisation ----------------------------------------------------------------------
+ * Row sums of a CSR in float64 (val NULL = row counts).  First half of normalize_adj
+ * (/root/reference/utils.py:427).  add_identity != 0 computes the sums of `mx + I`
+ * (utils.py:425-426) without materialising it: every sum grows by 1. */
+int disco_csr_rowsum_f64(const int64_t* rowptr, const float* val, int64_t n_rows, int add_identity,
+                         double* rowsum, void* stream);
+/* r = rowsum^-1/2 with inf -> 0 (utils.py:428-429), then
+ * val_out[e] = float32((r[row] * val_in[e]) * r[col[e]]) in float64 (utils.py:430-432, :634).
+ * `rowsum` is overwritten with r.  val_in NULL = all 1; val_out may alias val_in.
+ * add_identity != 0: entries with col == row get +1 in float64 before scaling (the diagonal of
+ * `mx + I`); the CSR must then hold a (possibly zero-valued) diagonal entry in every row. */
+int disco_gcn_norm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val_in,
+                           int64_t n_rows, int add_identity, double* rowsum, float* val_out,
+                           void* stream);
+
+/* gcn_norm, edge-index branch (/root/reference/utils.py:242-247; copy at
+ * /root/reference/models/convs_large/gcn_conv.py:65-70).
+ * Unweighted degree: deg[i] = #edges with idx == i, exact integers, then deg -> float32.
+ * Replaces torch_scatter.scatter_add at utils.py:244 for edge_weight=None. */
+int disco_degree_count_f32(const int64_t* idx, int64_t E, int64_t N, float* deg, void* stream);
+/* Weighted degree with the CPU reference's summation order: `order` is a stable argsort of
+ * idx and `segptr` int64[N+1] its segment pointers; deg[i] = sequential float32 sum of
+ * w[order[segptr[i]..segptr[i+1])] -- bit-identical to a serial scatter_add in edge order. */
+int disco_degree_ordered_f32(const int64_t* segptr, const int64_t* order, const float* w,
+                             int64_t N, float* deg, void* stream);
+/* dis = deg^-1/2 (inf -> 0) in place (utils.py:245-246), float32, 1/sqrt correctly rounded. */
+int disco_inv_sqrt_f32(float* deg, int64_t N, void* stream);
+/* w_out[e] = (dis[row[e]] * w_in[e]) * dis[col[e]], left to right (utils.py:247).
+ * w_in NULL = all 1. */
+int disco_gcn_norm_coo_apply_f32(const int64_t* row, const int64_t* col, const float* w_in,
+                                 int64_t E, const float* dis, float* w_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISCO_HIP_H */

@@ -1,0 +1,91 @@
+"""GPU parity of the normalisation kernels (A1 gcn_norm edge-index branch, A3 normalize_adj) with the
+CPU oracle.  Integer/ordered paths are checked bit for bit; the float64 path to 1 float32 ulp."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, orc
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "graph_golden.npz"))
+GRAPHS = ["path", "star", "loop0", "dup", "hub"]
+DEV = "cuda:0"
+
+
+def ulp_diff(a, b):
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+@pytest.mark.parametrize("name", GRAPHS)
+@pytest.mark.parametrize("loops", [False, True])
+def test_gcn_norm_golden_bit_exact(name, loops):
+    from disco_amd import utils
+    n, ei = int(GOLD[f"{name}_n"]), torch.from_numpy(GOLD[f"{name}_ei"]).to(DEV)
+    w = torch.from_numpy(GOLD[f"{name}_w"]).to(DEV) if f"{name}_w" in GOLD else None
+    ei2, out = utils.gcn_norm(ei, w, n, add_self_loops=loops)
+    key = f"{name}_gcn_norm_loop" if loops else f"{name}_gcn_norm_noloop"
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), GOLD[key].view(np.uint32))
+    if loops:
+        assert np.array_equal(ei2.cpu().numpy(), GOLD[f"{name}_gcn_norm_loop_ei"])
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("flow", ["source_to_target", "target_to_source"])
+def test_gcn_norm_random_bit_exact(weighted, flow):
+    from disco_amd import utils
+    rng = np.random.default_rng(12)
+    n, E = 5000, 200000
+    ei = rng.integers(0, n, (2, E))
+    ei[:, ei[1] == 9] = 10                     # node 9 isolated on both sides
+    ei[0, ei[0] == 9] = 11
+    w = rng.random(E).astype(np.float32) if weighted else None
+    _, ref = orc.gcn_norm_coo(ei, w, n, add_self_loops=False, flow=flow)
+    _, got = utils.gcn_norm(torch.from_numpy(ei).to(DEV), None if w is None else torch.from_numpy(w).to(DEV), n,
+                            add_self_loops=False, flow=flow)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", GRAPHS)
+def test_normalize_adj_tensor_golden(name):
+    from disco_amd import utils
+    n, ei = int(GOLD[f"{name}_n"]), GOLD[f"{name}_ei"]
+    w = GOLD[f"{name}_w"] if f"{name}_w" in GOLD else np.ones(ei.shape[1], np.float32)
+    adj = torch.sparse_coo_tensor(torch.from_numpy(ei), torch.from_numpy(w), (n, n)).to(DEV)
+    out = utils.normalize_adj_tensor(adj, sparse=True)
+    assert out.layout == torch.sparse_coo and out.dtype == torch.float32 and out.device.type == "cuda"
+    idx, val = out.indices().cpu().numpy(), out.values().cpu().numpy()
+    keep = val != 0
+    order = np.lexsort((GOLD[f"{name}_normadj_col"], GOLD[f"{name}_normadj_row"]))
+    assert np.array_equal(idx[0][keep], GOLD[f"{name}_normadj_row"][order])
+    assert np.array_equal(idx[1][keep], GOLD[f"{name}_normadj_col"][order])
+    assert ulp_diff(val[keep], GOLD[f"{name}_normadj_val"][order]).max() <= 1
+    # and the adj_t the convolution receives (LargeScaleCondensing.py:486)
+    adj_t = utils.to_adj_t(out)
+    assert adj_t.sparse_sizes() == (n, n)
+
+
+def test_normalize_adj_random_vs_scipy_oracle():
+    from disco_amd import SparseTensor, utils
+    rng = np.random.default_rng(5)
+    n, E = 3000, 40000
+    row, col = rng.integers(0, n, E), rng.integers(0, n, E)
+    val = (rng.random(E) + 0.1).astype(np.float32)
+    for zero_has_loop in (False, True):
+        r, c, v = row.copy(), col.copy(), val.copy()
+        if zero_has_loop:
+            r[0], c[0] = 0, 0
+        else:
+            keep = ~((r == 0) & (c == 0))
+            r, c, v = r[keep], c[keep], v[keep]
+        rr, cc, vv = orc.normalize_adj_scipy(r, c, v, n)
+        adj = torch.sparse_coo_tensor(torch.from_numpy(np.stack([r, c])), torch.from_numpy(v), (n, n)).to(DEV)
+        out = utils.normalize_adj_tensor(adj, sparse=True)
+        idx, got = out.indices().cpu().numpy(), out.values().cpu().numpy()
+        dense_ref = np.zeros((n, n), np.float32)
+        dense_ref[rr, cc] = vv
+        ref = dense_ref[idx[0], idx[1]]
+        # duplicate entries are summed in float32 in a different order than scipy: allow 2 ulp
+        assert ulp_diff(got, ref).max() <= 2
+        assert np.count_nonzero(got) == np.count_nonzero(vv)

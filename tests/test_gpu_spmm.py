@@ -1,0 +1,202 @@
+"""GPU parity of the HIP SpMM / K-hop / max path against the CPU oracle, through the C ABI
+(disco_amd.ops -> ctypes -> libdisco_hip.so).  Tolerance: see helpers.RTOL (fp32, 1e-5 forward error)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, assert_fwd_close, csr_to_coo, orc, random_csr
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "graph_golden.npz"))
+GRAPHS = ["path", "star", "loop0", "dup", "hub"]
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def to_adj(rowptr, col, val, n_cols):
+    from disco_amd import SparseTensor
+    return SparseTensor(rowptr=torch.from_numpy(rowptr).to(dev()), col=torch.from_numpy(col).to(dev()),
+                        value=None if val is None else torch.from_numpy(val).to(dev()),
+                        sparse_sizes=(len(rowptr) - 1, n_cols), is_sorted=True)
+
+
+def test_extension_is_loaded_from_tree():
+    from disco_amd import _lib
+    lib = _lib.load()
+    assert lib.disco_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "disco_amd/csrc/libdisco_hip.so" in maps
+    assert len({l.split()[-1] for l in maps.splitlines() if "libamdhip64" in l}) == 1
+
+
+@pytest.mark.parametrize("name", GRAPHS)
+def test_golden_graphs(name):
+    from disco_amd import ops
+    n = int(GOLD[f"{name}_n"])
+    rowptr, col, val = GOLD[f"{name}_adjt_rowptr"], GOLD[f"{name}_adjt_col"], GOLD[f"{name}_adjt_val"]
+    adj = to_adj(rowptr, col, val, n)
+    Fs = (1, 3, 100, 128, 602) if n <= 8 else (1, 3, 128)
+    for F in Fs:
+        x = GOLD[f"{name}_x{F}"]
+        xd = torch.from_numpy(x).to(dev())
+        bound1 = orc.spmm_abs_bound(rowptr, col, val, x)
+        for K in (1, 2):
+            y = ops.khop(adj, xd, K).cpu().numpy()
+            bound = bound1 if K == 1 else orc.spmm_abs_bound(rowptr, col, val, bound1)
+            assert_fwd_close(y, GOLD[f"{name}_khop{K}_F{F}_f64"], bound * K, what=f"{name} K={K} F={F}")
+        if F in (3, 128):
+            mx = ops.max_aggregate(adj, xd).cpu().numpy()
+            assert np.array_equal(mx, GOLD[f"{name}_max_F{F}"]), "max aggregation must be bit exact"
+            ym = ops.spmm(adj, xd, "mean").cpu().numpy()
+            assert_fwd_close(ym, GOLD[f"{name}_mean_F{F}_f64"], bound1, what=f"{name} mean F={F}")
+
+
+SHAPES = [  # n_rows, n_cols, avg_deg, F, hubs
+    (300, 300, 6, 1, [(0, 100)]),
+    (257, 400, 3, 3, []),
+    (1000, 1000, 14, 47, [(17, 5000)]),
+    (777, 900, 9, 100, [(5, 2500), (6, 9000)]),
+    (1500, 1500, 7, 128, [(1, 20000)]),
+    (640, 640, 20, 256, [(2, 3000)]),
+    (400, 512, 40, 602, [(3, 10000)]),
+    (150, 200, 5, 1300, [(9, 2100)]),
+    (90, 90, 4, 2600, []),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: f"n{s[0]}_F{s[3]}")
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_spmm_parity(shape, reduce, weighted):
+    from disco_amd import ops
+    n_rows, n_cols, avg, F, hubs = shape
+    rowptr, col, val = random_csr(n_rows, n_cols, avg, seed=n_rows + F, hubs=hubs, weighted=weighted)
+    x = np.random.default_rng(F).standard_normal((n_cols, F)).astype(np.float32)
+    adj = to_adj(rowptr, col, val, n_cols)
+    xd = torch.from_numpy(x).to(dev())
+    y = ops.spmm(adj, xd, reduce).cpu().numpy()
+    assert y.shape == (n_rows, F)
+    if reduce == "max":
+        ref = c_oracle.spmm_csr_f32(rowptr, col, val, x, "max")
+        assert np.array_equal(y, ref), "max is order independent: bit exact"
+        return
+    y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x, want_bound=True)
+    if reduce == "mean":
+        cnt = np.maximum(np.diff(rowptr), 1)[:, None].astype(np.float64)
+        y64, bound = y64 / cnt, bound / cnt
+    assert_fwd_close(y, y64, bound, what=f"{reduce} {shape}")
+    if not weighted and reduce == "sum":
+        # unweighted sums of small integers are exact in fp32: must match bit for bit
+        xi = np.random.default_rng(1).integers(-8, 8, (n_cols, F)).astype(np.float32)
+        yi = ops.spmm(adj, torch.from_numpy(xi).to(dev()), "sum").cpu().numpy()
+        assert np.array_equal(yi, c_oracle.spmm_csr_f32(rowptr, col, None, xi, "sum"))
+
+
+@pytest.mark.parametrize("sched", [True, False])
+def test_schedule_and_natural_order_agree(sched):
+    from disco_amd import ops
+    rowptr, col, val = random_csr(2000, 2000, 12, seed=11, hubs=[(4, 30000), (1999, 2049)], weighted=True)
+    x = np.random.default_rng(2).standard_normal((2000, 96)).astype(np.float32)
+    adj = to_adj(rowptr, col, val, 2000)
+    y = ops.spmm_raw(adj, torch.from_numpy(x).to(dev()), "sum", use_schedule=sched).cpu().numpy()
+    y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x, want_bound=True)
+    assert_fwd_close(y, y64, bound)
+    if sched:
+        ws, info = adj.schedule()
+        assert info.n_hub_rows == 2 and info.n_multi_rows == 1 and info.max_row_nnz == 30000
+        assert info.n_hub_pieces == 1 + info.n_hub_partials and info.n_hub_partials == 4
+        # deterministic: two launches give identical bits
+        y2 = ops.spmm_raw(adj, torch.from_numpy(x).to(dev()), "sum").cpu().numpy()
+        assert np.array_equal(y, y2)
+
+
+def test_strided_and_unaligned_operands():
+    # ld = 602 (8-byte rows -> 64-bit loads), ld = 601 (scalar loads), and a padded ld = 608 view
+    from disco_amd import ops
+    rowptr, col, val = random_csr(300, 300, 10, seed=5, hubs=[(7, 2500)], weighted=True)
+    adj = to_adj(rowptr, col, val, 300)
+    for F, ld in ((602, 602), (601, 601), (602, 608), (100, 100), (127, 127)):
+        x = np.random.default_rng(F).standard_normal((300, F)).astype(np.float32)
+        buf = torch.zeros((300, ld), device=dev())
+        buf[:, :F] = torch.from_numpy(x).to(dev())
+        xd = buf[:, :F]
+        out = torch.full((300, ld), 7.0, device=dev())[:, :F]
+        y = ops.spmm_raw(adj, xd, "sum", out=out).cpu().numpy()
+        y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x, want_bound=True)
+        assert_fwd_close(y, y64, bound, what=f"F={F} ld={ld}")
+
+
+@pytest.mark.parametrize("K,slices", [(1, 1), (2, 1), (2, 3), (3, 2), (4, 5)])
+def test_khop_matches_repeated_oracle(K, slices):
+    from disco_amd import ops
+    n, F = 1200, 200
+    rowptr, col, val = random_csr(n, n, 8, seed=21, hubs=[(0, 4000)], weighted=True)
+    val = (val * 0.2).astype(np.float32)
+    x = np.random.default_rng(3).standard_normal((n, F)).astype(np.float32)
+    adj = to_adj(rowptr, col, val, n)
+    y = ops.khop(adj, torch.from_numpy(x).to(dev()), K, n_col_slices=slices).cpu().numpy()
+    y64 = orc.khop_csr(rowptr, col, val, x, K, np.float64)
+    bound = np.abs(x).astype(np.float64)
+    for _ in range(K):
+        bound = orc.spmm_abs_bound(rowptr, col, val, bound)
+    assert_fwd_close(y, y64, bound * K, what=f"K={K} slices={slices}")
+    # slicing the columns must not change a single bit
+    y1 = ops.khop(adj, torch.from_numpy(x).to(dev()), K, n_col_slices=1).cpu().numpy()
+    assert np.array_equal(y, y1)
+
+
+def test_empty_and_degenerate_inputs():
+    from disco_amd import SparseTensor, ops
+    adj = SparseTensor(rowptr=torch.zeros(6, dtype=torch.int64, device=dev()), col=torch.zeros(0, dtype=torch.int64, device=dev()),
+                       sparse_sizes=(5, 5), is_sorted=True)
+    x = torch.randn(5, 16, device=dev())
+    assert torch.equal(ops.spmm(adj, x, "sum"), torch.zeros(5, 16, device=dev()))
+    assert torch.equal(ops.spmm(adj, x, "max"), torch.zeros(5, 16, device=dev()))
+    assert ops.spmm(adj, torch.randn(5, 0, device=dev()), "sum").shape == (5, 0)
+    adj0 = SparseTensor(rowptr=torch.zeros(1, dtype=torch.int64, device=dev()), col=torch.zeros(0, dtype=torch.int64, device=dev()),
+                        sparse_sizes=(0, 5), is_sorted=True)
+    assert ops.spmm(adj0, x, "sum").shape == (0, 16)
+    with pytest.raises(ValueError):
+        ops.spmm(adj, torch.randn(3, 16, device=dev()), "sum")
+    with pytest.raises(TypeError):
+        ops.spmm(adj, x.double(), "sum")
+
+
+def test_full_size_properties_arxiv_shaped():
+    """BASELINE config 1 (ogbn-arxiv shape) at full size: properties that need no oracle run --
+    linearity, A*1 == row sums, and agreement of a 4096-row sample with the float64 oracle."""
+    from disco_amd import SparseTensor, graphgen, ops, utils
+    spec = graphgen.SPECS["arxiv"]
+    row, col = graphgen.powerlaw_edges(spec.n_nodes, spec.nnz, spec.skew, spec.seed, device=dev())
+    n = spec.n_nodes
+    adj = SparseTensor(row=row, col=col, value=None, sparse_sizes=(n, n), is_sorted=True)
+    adj = utils.normalize_adj_csr(adj)            # +I, row degree, float64 -> float32 (utils.py:406-435)
+    F = spec.feat
+    x = graphgen.features(n, F, spec.seed, device=dev())
+    z = graphgen.features(n, F, spec.seed + 1, device=dev())
+    y = ops.khop(adj, x, 2)
+    yz = ops.khop(adj, z, 2)
+    ylin = ops.khop(adj, 0.5 * x - 2.0 * z, 2)
+    scale = ops.khop(adj.set_value(adj.storage.value().abs()), x.abs() + 2 * z.abs(), 2)
+    assert bool(((ylin - (0.5 * y - 2.0 * yz)).abs() <= 4e-5 * scale + 1e-30).all())
+    ones = torch.ones(n, 4, device=dev())
+    rs = torch.zeros(n, dtype=torch.float64, device=dev()).index_add_(0, adj.storage.row(), adj.storage.value().double())
+    a1 = ops.spmm(adj, ones, "sum")[:, 0].double()
+    assert bool(((a1 - rs).abs() <= 1e-5 * rs.abs() + 1e-12).all())
+    # sample of rows against the float64 oracle
+    rp, c, v = (t.cpu().numpy() for t in adj.csr())
+    xs = x.cpu().numpy()
+    y1 = ops.spmm(adj, x, "sum").cpu().numpy()
+    rows = np.random.default_rng(0).choice(n, 4096, replace=False)
+    rows.sort()
+    sub_rp = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.cumsum(rp[rows + 1] - rp[rows], out=sub_rp[1:])
+    idx = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in rows])
+    y64, bound = c_oracle.spmm_csr_f64acc(sub_rp, c[idx], v[idx], xs, want_bound=True)
+    assert_fwd_close(y1[rows], y64, bound, what="arxiv-shaped sample")

@@ -1,0 +1,72 @@
+"""Host-side logic on CPU: the CSR container, the synthetic generators and the no-fallback rule."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import orc
+from disco_amd import SparseTensor, graphgen, ops
+from disco_amd.models.convs_large import GCNConv, SGConv
+from disco_amd.models.convs_large.message_passing import _EdgeListCache
+
+
+def test_sparse_tensor_matches_oracle_layout():
+    rng = np.random.default_rng(0)
+    n, E = 50, 400
+    row, col = rng.integers(0, n, E), rng.integers(0, n, E)
+    val = rng.random(E).astype(np.float32)
+    st = SparseTensor(row=torch.from_numpy(row), col=torch.from_numpy(col), value=torch.from_numpy(val), sparse_sizes=(n, n))
+    rp, c, v = orc.coo_to_csr(row, col, val, n)
+    assert np.array_equal(st.storage.rowptr().numpy(), rp)
+    assert np.array_equal(st.storage.col().numpy(), c)
+    assert np.array_equal(st.storage.value().numpy(), v)
+    t = st.t()
+    rp2, c2, v2 = orc.adj_t_from_coo(row, col, val, n)
+    assert np.array_equal(t.csr()[0].numpy(), rp2) and np.array_equal(t.csr()[1].numpy(), c2)
+    assert np.array_equal(np.sort(t.csr()[2].numpy()), np.sort(v2))
+    assert t.t() is st and st.size(0) == n and st.nnz() == E and st.sparse_sizes() == (n, n)
+    r3, c3, v3 = st.coo()
+    assert np.array_equal(r3.numpy() * n + c3.numpy(), np.sort(row * n + col))
+
+
+def test_sparse_tensor_rejects_bad_indices():
+    with pytest.raises(ValueError):
+        SparseTensor(row=torch.tensor([0, 1]), col=torch.tensor([0, 9]), sparse_sizes=(2, 3))
+    with pytest.raises(ValueError):
+        SparseTensor(rowptr=torch.tensor([0, 1, 5]), col=torch.tensor([0, 1]), sparse_sizes=(2, 3))
+
+
+def test_edge_list_cache_is_stable_in_edge_order():
+    ei = torch.tensor([[3, 1, 2, 0, 1], [0, 0, 1, 0, 1]])
+    struct, perm = _EdgeListCache().get(ei, 4, 4)
+    assert struct.csr()[0].tolist() == [0, 3, 5, 5, 5]
+    assert struct.csr()[1].tolist() == [3, 1, 0, 2, 1]      # sources in original edge order per target
+    assert perm.tolist() == [0, 1, 3, 2, 4]
+
+
+def test_generator_is_deterministic_and_symmetric():
+    r1, c1 = graphgen.powerlaw_edges(2000, 30000, 0.8, seed=5)
+    r2, c2 = graphgen.powerlaw_edges(2000, 30000, 0.8, seed=5)
+    assert torch.equal(r1, r2) and torch.equal(c1, c2)
+    k = set((r1 * 2000 + c1).tolist())
+    assert all((c * 2000 + r) in k for r, c in zip(r1.tolist()[:500], c1.tolist()[:500]))
+    assert not bool((r1 == c1).any())
+    assert len(k) == r1.numel()                             # no duplicates
+    deg = torch.bincount(r1, minlength=2000)
+    assert deg.max() > 8 * deg.float().mean()               # skewed
+    r3, c3 = graphgen.powerlaw_edges(500, 4000, 0.0, seed=1, symmetric=False, n_cols=4000)
+    assert int(c3.max()) < 4000 and int(r3.max()) < 500
+
+
+def test_no_cpu_fallback():
+    st = SparseTensor(row=torch.tensor([0, 1]), col=torch.tensor([1, 0]), sparse_sizes=(2, 2))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        ops.spmm(st, torch.ones(2, 4))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        SGConv(4, 3, K=2)(torch.ones(2, 4), st)
+
+
+def test_module_state_dict_keys_match_reference():
+    # convs.{i}.lin.weight, convs.{i}.bias (GCN) / lin.{weight,bias} (SGC)
+    assert sorted(GCNConv(8, 4).state_dict()) == ["bias", "lin.weight"]
+    assert sorted(SGConv(8, 4, K=2).state_dict()) == ["lin.bias", "lin.weight"]
+    assert SGConv(8, 4).K == 3
