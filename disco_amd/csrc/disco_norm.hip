@@ -16,31 +16,41 @@ static thread_local int g_last_hip_error = 0;
 void set_last_hip_error(int e) { g_last_hip_error = e; }
 Tuning& tuning() { static Tuning t; return t; }
 
-// ---- CSR row sums in float64: 16 lanes per row, fixed-order tree ---------------------------------
-__global__ __launch_bounds__(256) void k_csr_rowsum_f64(const int64_t* __restrict__ rowptr, const float* __restrict__ val,
-                                                        int64_t n_rows, int add_identity, double* __restrict__ out) {
+// ---- CSR row sums ------------------------------------------------------------------------------
+// add_identity != 0: sums of `mx + I` in float64 (scipy promotes float32 + eye() to float64,
+//                    utils.py:426-427); 16 lanes per row, fixed-order tree.
+// add_identity == 0: scipy keeps the float32 matrix in float32 all the way (utils.py:427-432), and its
+//                    row sum is a sequential float32 accumulation in CSR order: one lane per row.
+__global__ __launch_bounds__(256) void k_csr_rowsum(const int64_t* __restrict__ rowptr, const float* __restrict__ val,
+                                                    int64_t n_rows, int add_identity, double* __restrict__ out) {
   const int gl = threadIdx.x & 15;
   int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-  double s = 0.0;
   int64_t b = 0, e = 0;
   if (row < n_rows) { b = rowptr[row]; e = rowptr[row + 1]; }
-  if (val) {
-    for (int64_t i = b + gl; i < e; i += 16) s += (double)val[i];
-  } else {
-    s = 0.0;
+  if (!add_identity) {
+    if (row < n_rows && gl == 0) {
+      float s = 0.0f;
+      if (val) { for (int64_t i = b; i < e; ++i) s += val[i]; }
+      else s = (float)(e - b);
+      out[row] = (double)s;
+    }
+    return;
   }
+  double s = 0.0;
+  if (val) { for (int64_t i = b + gl; i < e; i += 16) s += (double)val[i]; }
   for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
   if (!val) s = (double)(e - b);
-  if (add_identity) s += 1.0;  // mx + I (utils.py:426): every row sum grows by one
+  s += 1.0;  // mx + I (utils.py:426): every row sum grows by one
   if (row < n_rows && gl == 0) out[row] = s;
 }
 
-__global__ __launch_bounds__(256) void k_inv_sqrt_f64(double* __restrict__ d, int64_t n) {
+__global__ __launch_bounds__(256) void k_inv_sqrt_norm(double* __restrict__ d, int64_t n, int add_identity) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  double v = d[i];
-  // numpy: np.power(rowsum, -1/2); inf -> 0 (utils.py:428-429).  A negative sum gives NaN there too.
-  double r = 1.0 / sqrt(v);
+  // np.power(rowsum, -1/2); inf -> 0 (utils.py:428-429).  In the float32 case the result is rounded to
+  // float32 (numpy's own float32 pow is only accurate to a few ulp and differs between CPUs).
+  double r = 1.0 / sqrt(d[i]);
+  if (!add_identity) r = (double)(float)r;
   if (isinf(r)) r = 0.0;
   d[i] = r;
 }
@@ -54,10 +64,15 @@ __global__ __launch_bounds__(256) void k_gcn_scale_csr(const int64_t* __restrict
   const int64_t b = rowptr[row], e = rowptr[row + 1];
   const double rr = r[row];
   for (int64_t i = b + gl; i < e; i += 16) {
-    double v = vin ? (double)vin[i] : 1.0;
     const int64_t c = col[i];
-    if (add_identity && c == row) v += 1.0;  // the diagonal entry of mx + I, in float64 like scipy
-    vout[i] = (float)((rr * v) * r[c]);
+    if (add_identity) {
+      double v = vin ? (double)vin[i] : 1.0;
+      if (c == row) v += 1.0;  // the diagonal entry of mx + I, in float64 like scipy
+      vout[i] = (float)((rr * v) * r[c]);
+    } else {
+      float v = vin ? vin[i] : 1.0f;
+      vout[i] = __fmul_rn(__fmul_rn((float)rr, v), (float)r[c]);  // float32 products, left to right
+    }
   }
 }
 
@@ -133,7 +148,7 @@ extern "C" int disco_csr_rowsum_f64(const int64_t* rowptr, const float* val, int
   if (n_rows < 0) return DISCO_EINVAL;
   if (n_rows == 0) return DISCO_OK;
   if (!rowptr || !rowsum) return DISCO_EINVAL;
-  hipLaunchKernelGGL(k_csr_rowsum_f64, dim3(blocks_for(n_rows, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr,
+  hipLaunchKernelGGL(k_csr_rowsum, dim3(blocks_for(n_rows, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr,
                      val, n_rows, add_identity, rowsum);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
@@ -145,7 +160,7 @@ extern "C" int disco_gcn_norm_csr_f32(const int64_t* rowptr, const int32_t* col,
   if (n_rows == 0) return DISCO_OK;
   if (!rowptr || !col || !rowsum || !val_out) return DISCO_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(k_inv_sqrt_f64, dim3(blocks_for(n_rows, 256)), dim3(256), 0, s, rowsum, n_rows);
+  hipLaunchKernelGGL(k_inv_sqrt_norm, dim3(blocks_for(n_rows, 256)), dim3(256), 0, s, rowsum, n_rows, add_identity);
   hipLaunchKernelGGL(k_gcn_scale_csr, dim3(blocks_for(n_rows, 16)), dim3(256), 0, s, rowptr, col, val_in, n_rows,
                      add_identity, (const double*)rowsum, val_out);
   DISCO_CHECK_LAUNCH();

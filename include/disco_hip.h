@@ -101,7 +101,8 @@ int disco_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* v
  * (/root/reference/models/convs_large/sg_conv.py:74-77).  tmp0/tmp1 are caller-owned
  * [n_rows, ldt] ping-pong buffers (tmp0 needed for K>=2, tmp1 for K>=3).
  * n_col_slices >= 1 runs the K hops independently on column slices of x (each slice's
- * working set then fits the 256 MiB Infinity Cache); results are identical for any value. */
+ * working set then fits the 256 MiB Infinity Cache).  Rows below the hub threshold give the same
+ * bits for any value; hub rows differ by rounding (their partial sums follow the lane-group width). */
 int disco_khop_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n,
                        int K, const float* x, int64_t ldx, float* y, int64_t ldy, float* tmp0,
                        float* tmp1, int64_t ldt, int64_t F, int n_col_slices,
@@ -109,16 +110,22 @@ int disco_khop_csr_f32(const int64_t* rowptr, const int32_t* col, const float* v
                        size_t spmm_ws_bytes, void* stream);
 
 /* ---- normalisation ----------------------------------------------------------------------
- * Row sums of a CSR in float64 (val NULL = row counts).  First half of normalize_adj
- * (/root/reference/utils.py:427).  add_identity != 0 computes the sums of `mx + I`
- * (utils.py:425-426) without materialising it: every sum grows by 1. */
+ * normalize_adj (/root/reference/utils.py:406-435) on a CSR whose duplicates are already summed.
+ * scipy's dtype promotion decides the arithmetic, and the kernels follow it:
+ *   add_identity != 0  (node 0 has no self-loop, utils.py:425-426): `mx + sp.eye(n)` is float64, so
+ *       row sums, r = rowsum^-1/2 and (r[row]*v)*r[col] are float64 with one rounding to float32
+ *       (utils.py:634).  The 1 on the diagonal is added on the fly: the CSR must hold a (possibly
+ *       zero-valued) diagonal entry in every row.
+ *   add_identity == 0  (node 0 has a self-loop): the float32 matrix stays float32 throughout: row
+ *       sums are sequential float32 additions in CSR order, r is rounded to float32, the products
+ *       are float32, left to right.  (numpy's float32 pow is only accurate to a few ulp and
+ *       CPU-dependent; r here is the correctly rounded value.)
+ * disco_csr_rowsum_f64 writes the row sums (as doubles in both modes; val NULL = row counts). */
 int disco_csr_rowsum_f64(const int64_t* rowptr, const float* val, int64_t n_rows, int add_identity,
                          double* rowsum, void* stream);
-/* r = rowsum^-1/2 with inf -> 0 (utils.py:428-429), then
- * val_out[e] = float32((r[row] * val_in[e]) * r[col[e]]) in float64 (utils.py:430-432, :634).
- * `rowsum` is overwritten with r.  val_in NULL = all 1; val_out may alias val_in.
- * add_identity != 0: entries with col == row get +1 in float64 before scaling (the diagonal of
- * `mx + I`); the CSR must then hold a (possibly zero-valued) diagonal entry in every row. */
+/* r = rowsum^-1/2 with inf -> 0 (utils.py:428-429), then val_out[e] = r[row] * val_in[e] * r[col[e]]
+ * (utils.py:430-432) in the arithmetic described above.  `rowsum` is overwritten with r.
+ * val_in NULL = all 1; val_out may alias val_in. */
 int disco_gcn_norm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val_in,
                            int64_t n_rows, int add_identity, double* rowsum, float* val_out,
                            void* stream);

@@ -97,9 +97,13 @@ def normalize_adj_scipy(row, col, val, n):
     * ``sp.csr_matrix((values, indices))`` sums duplicate entries (:656).
     * ``if mx[0, 0] == 0: mx = mx + I`` -- self-loops are added to EVERY node iff
       node 0 has none (:425-426).
-    * ``r = rowsum ** -1/2`` over ROW sums, inf -> 0, float64 (:427-429).
-    * ``diag(r) @ mx @ diag(r)`` in float64 (:430-432), one rounding to float32
-      in ``.astype(np.float32)`` (:634).
+    * ``r = rowsum ** -1/2`` over ROW sums, inf -> 0 (:427-429);
+      ``diag(r) @ mx @ diag(r)`` (:430-432); ``.astype(np.float32)`` (:634).
+    * dtype quirk (scipy promotion, verified here): when the identity is added the
+      matrix becomes float64 and all of the above runs in float64 with one final
+      rounding; when it is NOT added (node 0 has a self-loop) the float32 matrix
+      stays float32 -- sequential float32 row sums, numpy's float32 ``power``
+      (a few ulp off correctly rounded, CPU dependent) and float32 products.
     Returns COO ``(row, col, val_f32)`` in scipy's ``tocoo()`` order.
     """
     mx = sp.csr_matrix((np.asarray(val), (np.asarray(row), np.asarray(col))), shape=(n, n))

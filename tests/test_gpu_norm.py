@@ -60,17 +60,35 @@ def test_normalize_adj_tensor_golden(name):
     order = np.lexsort((GOLD[f"{name}_normadj_col"], GOLD[f"{name}_normadj_row"]))
     assert np.array_equal(idx[0][keep], GOLD[f"{name}_normadj_row"][order])
     assert np.array_equal(idx[1][keep], GOLD[f"{name}_normadj_col"][order])
-    assert ulp_diff(val[keep], GOLD[f"{name}_normadj_val"][order]).max() <= 1
+    # loop0: node 0 has a self-loop -> scipy's float32 path with numpy's few-ulp float32 pow (see below)
+    assert ulp_diff(val[keep], GOLD[f"{name}_normadj_val"][order]).max() <= (4 if name == "loop0" else 1)
     # and the adj_t the convolution receives (LargeScaleCondensing.py:486)
     adj_t = utils.to_adj_t(out)
     assert adj_t.sparse_sizes() == (n, n)
 
 
+def _f32_path_exact_rsqrt(r, c, v, n):
+    """normalize_adj when node 0 HAS a self-loop: scipy keeps float32 (row sum sequential in CSR order,
+    float32 products); r = correctly rounded rowsum^-1/2 instead of numpy's few-ulp float32 pow."""
+    import scipy.sparse as sp
+    A = sp.csr_matrix((v, (r, c)), shape=(n, n))
+    A.sort_indices()
+    rs = np.array(A.tolil().sum(1)).ravel()
+    assert rs.dtype == np.float32
+    with np.errstate(divide="ignore"):
+        ri = (1.0 / np.sqrt(rs.astype(np.float64))).astype(np.float32)
+    ri[np.isinf(ri)] = 0
+    coo = A.tocoo()
+    return coo.row, coo.col, (ri[coo.row] * coo.data) * ri[coo.col]
+
+
 def test_normalize_adj_random_vs_scipy_oracle():
-    from disco_amd import SparseTensor, utils
+    from disco_amd import utils
     rng = np.random.default_rng(5)
     n, E = 3000, 40000
-    row, col = rng.integers(0, n, E), rng.integers(0, n, E)
+    key = np.unique(rng.integers(0, n * n, E))      # no duplicate entries: their float32 sum order is
+    row, col = key // n, key % n                     # scipy's business (covered by the golden `dup` graph)
+    E = len(key)
     val = (rng.random(E) + 0.1).astype(np.float32)
     for zero_has_loop in (False, True):
         r, c, v = row.copy(), col.copy(), val.copy()
@@ -86,6 +104,16 @@ def test_normalize_adj_random_vs_scipy_oracle():
         dense_ref = np.zeros((n, n), np.float32)
         dense_ref[rr, cc] = vv
         ref = dense_ref[idx[0], idx[1]]
-        # duplicate entries are summed in float32 in a different order than scipy: allow 2 ulp
-        assert ulp_diff(got, ref).max() <= 2
         assert np.count_nonzero(got) == np.count_nonzero(vv)
+        if not zero_has_loop:
+            # mx + I is float64 in scipy: float64 row sums in another order, one rounding to float32
+            assert ulp_diff(got, ref).max() <= 1
+        else:
+            # no identity: scipy stays in float32 and numpy's float32 pow is a few ulp off the correctly
+            # rounded value (and CPU dependent), so the literal oracle is matched to 4 ulp; with a correctly
+            # rounded r the float32 path is reproduced bit for bit.
+            assert ulp_diff(got, ref).max() <= 4
+            er, ec, ev = _f32_path_exact_rsqrt(r, c, v, n)
+            dense = np.zeros((n, n), np.float32)
+            dense[er, ec] = ev
+            assert np.array_equal(got.view(np.uint32), dense[idx[0], idx[1]].view(np.uint32))
