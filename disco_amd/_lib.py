@@ -23,7 +23,8 @@ class ScheduleInfo(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_rows", "nnz", "hub_threshold", "hub_piece", "n_hub_rows", "n_hub_pieces", "n_hub_partials",
         "n_multi_rows", "max_row_nnz", "off_perm", "off_piece_row", "off_piece_begin", "off_piece_end",
-        "off_piece_slot", "off_multi_row", "off_multi_first", "ws_bytes")]
+        "off_piece_slot", "off_multi_row", "off_multi_first", "ws_bytes",
+        "sweep_windows", "sweep_window_rows", "sweep_count_padded", "sweep_n_cols")] + [("sweep_ws", C.c_void_p)]
 
 
 _SIGNATURES = {
@@ -34,6 +35,9 @@ _SIGNATURES = {
     "disco_schedule_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
     "disco_schedule_build": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_size_t,
                                      C.POINTER(ScheduleInfo), c_void_p]),
+    "disco_sweep_workspace_bytes": (c_size_t, [C.POINTER(ScheduleInfo), c_int64, c_int64]),
+    "disco_sweep_build": (c_int, [c_void_p, c_void_p, c_void_p, C.POINTER(ScheduleInfo), c_int64, c_int64, c_void_p, c_size_t,
+                                  c_void_p]),
     "disco_spmm_workspace_bytes": (c_size_t, [C.POINTER(ScheduleInfo), c_int64]),
     "disco_spmm_csr_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                    c_int64, c_int, c_void_p, C.POINTER(ScheduleInfo), c_void_p, c_size_t, c_void_p]),

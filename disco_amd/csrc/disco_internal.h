@@ -13,6 +13,8 @@ struct Tuning {
   int force_g = 0;    // 0 = automatic
   int force_nv = 0;   // 0 = automatic
   int max_vec = 0;    // 0 = 4
+  int no_sweep = 0;   // 1 = never use the L2-blocked sweep kernel
+  int sweep_blocks_per_cu = 0;  // 0 = 4
 };
 
 Tuning& tuning();

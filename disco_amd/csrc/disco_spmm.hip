@@ -283,12 +283,164 @@ __global__ __launch_bounds__(256) void k_hub_combine(const int64_t* __restrict__
   }
 }
 
+// ---- L2-blocked sweep: rows below the hub threshold of DENSE-ish graphs -------------------------------
+// Measured on MI355X: a row gather that misses the XCD's L2 is served at ~7.5 TB/s
+// chip-wide whether it comes from the Infinity Cache or from HBM, a gather that hits L2 at ~27 TB/s.
+// This kernel makes the gathers hit L2: the source rows are cut into WINDOWS of `window_rows` rows
+// (window_rows * slice bytes ~ 2 MB < 4 MiB L2), every wave owns R = 16 output rows whose sums stay in
+// registers, and ALL resident waves walk the windows in the same order at the same time, so that at any
+// moment the whole XCD gathers from one window.  Nothing synchronises the waves (correctness does not
+// depend on it): they start together, rows of one generation have the same degree class, and a wave
+// that runs ahead is the one that misses L2 and falls back.  wptr[w][pos] (uint32) is the offset inside
+// row `perm[first+pos]` of its first entry with col >= w * window_rows; entries of a row are visited in
+// CSR order, so the result has the same bits as k_spmm_rows.
+template <bool HASVAL>
+__global__ __launch_bounds__(256, 4) void k_spmm_sweep(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       const float* __restrict__ val, const float* __restrict__ x,
+                                                       int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
+                                                       const uint32_t* __restrict__ perm, int64_t first, int64_t count,
+                                                       const uint32_t* __restrict__ wptr, int64_t cp, int P,
+                                                       int64_t n_batches, int flags) {
+  constexpr int R = 16;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t total_waves = (int64_t)gridDim.x * 4;
+  const int li = lane < nvec ? lane : nvec - 1;
+  const float* xl = x + (int64_t)li * 4;
+  for (int64_t batch = wave_global; batch < n_batches; batch += total_waves) {
+    // Slot s of batch b is row position b + s * n_batches of the degree-sorted order: every batch gets
+    // one row of each of 16 degree quantiles, so all waves carry the same number of entries and walk
+    // the windows at the same pace.  Slot info lives in lanes 0..15 (lane s = slot s).
+    const int64_t p = batch + (int64_t)(lane & 15) * n_batches;
+    const bool valid = p < count;
+    const int64_t row = valid ? (int64_t)perm[first + p] : 0;
+    const int64_t rbeg = valid ? rowptr[row] : 0;
+    uint32_t cur = wptr[p];
+    f4 acc[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s) acc[s] = 0.0f;
+    for (int w = 0; w < P; ++w) {
+      const uint32_t nxt = wptr[(int64_t)(w + 1) * cp + p];
+      const int seglen = (int)(nxt - cur);
+      const int64_t eb = rbeg + cur;
+      cur = nxt;
+      if (__ballot(seglen > 0 && lane < 16) == 0) continue;
+      // cooperative (col, val) fetch: register r covers slots 4r..4r+3, 16 lanes (= 16 entries) per slot
+      int cj[4];
+      float vj[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int src = 4 * r + (lane >> 4);
+        const int k = lane & 15;
+        const int sl = __shfl(seglen, src);
+        const int64_t se = ((int64_t)__shfl((int)(eb >> 32), src) << 32) | (uint32_t)__shfl((int)(eb & 0xffffffffLL), src);
+        const bool ok = k < sl;
+        cj[r] = ok ? col[se + k] : 0;
+        vj[r] = (HASVAL && ok) ? val[se + k] : 0.0f;
+      }
+#pragma unroll
+      for (int s = 0; s < R; ++s) {
+        const int len = __builtin_amdgcn_readlane(seglen, s);
+        const int n16 = len < 16 ? len : 16;
+        const int lbase = 16 * (s & 3);
+        for (int k = 0; k < n16; k += 4) {
+          const int m = n16 - k;
+          f4 x0, x1, x2, x3;
+          float w0 = 1.0f, w1 = 1.0f, w2 = 1.0f, w3 = 1.0f;
+          {
+            const int c = __builtin_amdgcn_readlane(cj[s >> 2], lbase + k);
+            if (HASVAL) w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vj[s >> 2]), lbase + k));
+            x0 = *reinterpret_cast<const f4*>(xl + (int64_t)c * ldx);
+          }
+          if (m > 1) {
+            const int c = __builtin_amdgcn_readlane(cj[s >> 2], lbase + k + 1);
+            if (HASVAL) w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vj[s >> 2]), lbase + k + 1));
+            x1 = *reinterpret_cast<const f4*>(xl + (int64_t)c * ldx);
+          }
+          if (m > 2) {
+            const int c = __builtin_amdgcn_readlane(cj[s >> 2], lbase + k + 2);
+            if (HASVAL) w2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vj[s >> 2]), lbase + k + 2));
+            x2 = *reinterpret_cast<const f4*>(xl + (int64_t)c * ldx);
+          }
+          if (m > 3) {
+            const int c = __builtin_amdgcn_readlane(cj[s >> 2], lbase + k + 3);
+            if (HASVAL) w3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vj[s >> 2]), lbase + k + 3));
+            x3 = *reinterpret_cast<const f4*>(xl + (int64_t)c * ldx);
+          }
+          vupdate<4, OP_SUM, HASVAL>(acc[s], w0, x0);
+          if (m > 1) vupdate<4, OP_SUM, HASVAL>(acc[s], w1, x1);
+          if (m > 2) vupdate<4, OP_SUM, HASVAL>(acc[s], w2, x2);
+          if (m > 3) vupdate<4, OP_SUM, HASVAL>(acc[s], w3, x3);
+        }
+        if (len > 16) {
+          // rare long segment: the remainder goes through the generic walker (same CSR order)
+          const int64_t se = ((int64_t)__builtin_amdgcn_readlane((int)(eb >> 32), s) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(eb & 0xffffffffLL), s);
+          f4 a1[1];
+          a1[0] = acc[s];
+          accumulate_range<4, 64, 1, OP_SUM, HASVAL>(se + 16, se + len, col, val, x, ldx, nvec, lane, a1);
+          acc[s] = a1[0];
+        }
+      }
+    }
+    const int64_t end_l = valid ? rowptr[row + 1] : 0;
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+      const int64_t rs = ((int64_t)__builtin_amdgcn_readlane((int)(row >> 32), s) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)(row & 0xffffffffLL), s);
+      const int64_t nb = ((int64_t)__builtin_amdgcn_readlane((int)(rbeg >> 32), s) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)(rbeg & 0xffffffffLL), s);
+      const int64_t ne = ((int64_t)__builtin_amdgcn_readlane((int)(end_l >> 32), s) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)(end_l & 0xffffffffLL), s);
+      if (lane < nvec && batch + (int64_t)s * n_batches < count) {
+        f4 a = acc[s];
+        f4* dst = reinterpret_cast<f4*>(y + rs * ldy + (int64_t)lane * 4);
+        if ((flags & FLAG_MEAN) && ne > nb) a = vdiv<4>(a, (float)(ne - nb));
+        if (flags & FLAG_ACCUM) a = *dst + a;
+        *dst = a;
+      }
+    }
+  }
+}
+
+// wptr[w][pos] for w in [0, P]: lower bound of w * window_rows among the (sorted) columns of row perm[first+pos]
+__global__ __launch_bounds__(256) void k_build_wptr(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                    const uint32_t* __restrict__ perm, int64_t first, int64_t count,
+                                                    int64_t cp, int64_t window_rows, int P, uint32_t* __restrict__ wptr,
+                                                    unsigned int* __restrict__ unsorted_flag) {
+  const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int w = blockIdx.y;
+  if (pos >= cp) return;
+  uint32_t out = 0;
+  if (pos < count) {
+    const int64_t row = perm[first + pos];
+    const int64_t b = rowptr[row], e = rowptr[row + 1];
+    if (w >= P) out = (uint32_t)(e - b);
+    else {
+      const int64_t target = (int64_t)w * window_rows;
+      int64_t lo = b, hi = e;
+      while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)col[mid] < target) lo = mid + 1; else hi = mid;
+      }
+      out = (uint32_t)(lo - b);
+    }
+    if (w == 0) {  // one thread per row also verifies that the row's columns are sorted
+      for (int64_t i = b + 1; i < e; ++i)
+        if (col[i] < col[i - 1]) { atomicOr(unsorted_flag, 1u); break; }
+    }
+  }
+  wptr[(int64_t)w * cp + pos] = out;
+}
+
 // ---- host-side dispatch -----------------------------------------------------------------------------
 struct SpmmArgs {
   const int64_t* rowptr; const int32_t* col; const float* val; int64_t n_rows;
   const float* x; int64_t ldx; float* y; int64_t ldy; int64_t F; int reduce;
   const char* sched; const disco_schedule_info* info; float* partial; int64_t ldp; hipStream_t stream;
 };
+
+static int device_cus();
 
 template <int VEC, int G, int NV, int OP, bool HASVAL>
 static int launch_cfg(const SpmmArgs& a, int nvec) {
@@ -317,7 +469,21 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       }
     }
   }
-  if (count > 0) {
+  bool swept = false;
+  if constexpr (VEC == 4 && NV == 1 && OP == OP_SUM) {
+    if (count > 0 && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && !tuning().no_sweep) {
+      const disco_schedule_info& s = *a.info;
+      const int64_t n_batches = (count + 15) / 16;
+      int64_t blocks = (n_batches + 3) / 4;
+      const int64_t cap = (int64_t)device_cus() * (tuning().sweep_blocks_per_cu > 0 ? tuning().sweep_blocks_per_cu : 4);
+      if (blocks > cap) blocks = cap;
+      hipLaunchKernelGGL((k_spmm_sweep<HASVAL>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col, a.val, a.x,
+                         a.ldx, a.y, a.ldy, nvec, perm, first, count, reinterpret_cast<const uint32_t*>(s.sweep_ws),
+                         s.sweep_count_padded, (int)s.sweep_windows, n_batches, mean);
+      swept = true;
+    }
+  }
+  if (count > 0 && !swept) {
     int64_t blocks = (count + 4 * RPW - 1) / (4 * RPW);
     if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
     hipLaunchKernelGGL((k_spmm_rows<VEC, G, NV, OP, HASVAL>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
@@ -356,6 +522,17 @@ static int launch_vec(const SpmmArgs& a, int nvec) {
   return DISCO_EUNSUPPORTED;
 }
 
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // Widest vector the operands allow: the leading dimensions and base addresses must keep every
@@ -376,7 +553,13 @@ int spmm_dispatch(const SpmmArgs& a0) {
   SpmmArgs a = a0;
   // Columns are processed in blocks of at most 5*64 vectors (one pass for F <= 1280 at VEC=4).
   int vec = pick_vec(a.x, a.ldx, a.y, a.ldy, a.partial, a.ldp, a.F);
-  const int64_t max_cols = (int64_t)5 * 64 * vec;
+  int64_t max_cols = (int64_t)5 * 64 * vec;
+  if (vec == 4 && a.reduce != DISCO_REDUCE_MAX && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && !tuning().no_sweep &&
+      a.F > 64) {
+    // the sweep kernel holds one float4 per lane: balanced column blocks of at most 256 floats (multiples of 32)
+    int64_t nblk = (a.F + 255) / 256;
+    max_cols = ((a.F + nblk - 1) / nblk + 31) / 32 * 32;
+  }
   for (int64_t c0 = 0; c0 < a0.F; c0 += max_cols) {
     int64_t f = a0.F - c0 < max_cols ? a0.F - c0 : max_cols;
     a.x = a0.x + c0; a.y = a0.y + c0; a.F = f;
@@ -394,6 +577,49 @@ int spmm_dispatch(const SpmmArgs& a0) {
 }  // namespace disco
 
 using namespace disco;
+
+extern "C" size_t disco_sweep_workspace_bytes(const disco_schedule_info* info, int64_t n_cols, int64_t window_rows) {
+  if (!info || n_cols <= 0 || window_rows <= 0) return 0;
+  const int64_t count = info->n_rows - info->n_hub_rows;
+  if (count <= 0) return 0;
+  const int64_t cp = (count + 15) / 16 * 16;
+  const int64_t P = (n_cols + window_rows - 1) / window_rows;
+  return (size_t)((P + 1) * cp) * sizeof(uint32_t) + 256;
+}
+
+extern "C" int disco_sweep_build(const int64_t* rowptr, const int32_t* col, const void* sched_ws, disco_schedule_info* info,
+                                 int64_t n_cols, int64_t window_rows, void* sweep_ws, size_t sweep_ws_bytes, void* stream_) {
+  if (!info || !rowptr || !sched_ws || n_cols <= 0 || window_rows <= 0) return DISCO_EINVAL;
+  info->sweep_ws = nullptr; info->sweep_windows = 0;
+  const int64_t count = info->n_rows - info->n_hub_rows;
+  if (count <= 0) return DISCO_OK;
+  if (info->hub_threshold >= 0xffffffffLL) return DISCO_EUNSUPPORTED;
+  size_t need = disco_sweep_workspace_bytes(info, n_cols, window_rows);
+  if (!sweep_ws || sweep_ws_bytes < need) return DISCO_EWORKSPACE;
+  if (!col && info->nnz > 0) return DISCO_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int64_t cp = (count + 15) / 16 * 16;
+  const int64_t P = (n_cols + window_rows - 1) / window_rows;
+  if (P + 1 > 65535) return DISCO_EUNSUPPORTED;
+  char* ws = static_cast<char*>(sweep_ws);
+  unsigned int* flag = reinterpret_cast<unsigned int*>(ws);
+  uint32_t* wptr = reinterpret_cast<uint32_t*>(ws + 256);
+  DISCO_HIP_TRY(hipMemsetAsync(flag, 0, 256, stream));
+  const uint32_t* perm = reinterpret_cast<const uint32_t*>(static_cast<const char*>(sched_ws) + info->off_perm);
+  hipLaunchKernelGGL(k_build_wptr, dim3((unsigned)((cp + 255) / 256), (unsigned)(P + 1)), dim3(256), 0, stream, rowptr, col, perm,
+                     info->n_hub_rows, count, cp, window_rows, (int)P, wptr, flag);
+  DISCO_CHECK_LAUNCH();
+  unsigned int h = 0;
+  DISCO_HIP_TRY(hipMemcpyAsync(&h, flag, sizeof(h), hipMemcpyDeviceToHost, stream));
+  DISCO_HIP_TRY(hipStreamSynchronize(stream));
+  if (h) return DISCO_EUNSUPPORTED;  // columns are not sorted inside the rows: the plain kernel stays in use
+  info->sweep_ws = wptr;
+  info->sweep_windows = P;
+  info->sweep_window_rows = window_rows;
+  info->sweep_count_padded = cp;
+  info->sweep_n_cols = n_cols;
+  return DISCO_OK;
+}
 
 extern "C" size_t disco_spmm_workspace_bytes(const disco_schedule_info* info, int64_t F) {
   if (!info || info->n_hub_partials <= 0 || F <= 0) return 0;

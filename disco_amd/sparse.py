@@ -20,6 +20,15 @@ import torch
 from . import _lib
 
 
+def sweep_window_rows(feat: int, window_bytes: int = 2 << 20) -> int:
+    """Source rows per L2 window for feature width `feat`: the kernels cut wide features into balanced
+    column blocks of at most 256 floats (multiples of 32) and one window of one block should take
+    ~2 MB of the XCD's 4 MiB L2."""
+    nblk = max(1, (feat + 255) // 256)
+    blk = max(32, ((feat + nblk - 1) // nblk + 31) // 32 * 32)
+    return max(64, window_bytes // (4 * blk))
+
+
 class _Storage:
     """``adj.storage`` facade: ``row()``, ``col()``, ``rowptr()``, ``value()``."""
 
@@ -76,6 +85,7 @@ class SparseTensor:
         self._sizes = sparse_sizes
         self._sched = None          # (ws tensor, ScheduleInfo)
         self._sched_key = None
+        self._sweep = None          # (window_rows, workspace tensor or None)
         self._t: Optional["SparseTensor"] = None
         self.storage = _Storage(self)
 
@@ -143,7 +153,7 @@ class SparseTensor:
 
     def set_value(self, value: Optional[torch.Tensor], layout: Optional[str] = None) -> "SparseTensor":
         out = SparseTensor(rowptr=self._rowptr, col=self._col32, value=value, sparse_sizes=self._sizes, is_sorted=True)
-        out._sched, out._sched_key = self._sched, self._sched_key
+        out._sched, out._sched_key, out._sweep = self._sched, self._sched_key, self._sweep
         return out
 
     def fill_value(self, fill: float, dtype=torch.float32) -> "SparseTensor":
@@ -187,12 +197,16 @@ class SparseTensor:
         return self._t
 
     # ---- device-side schedule -------------------------------------------------------------------
-    def schedule(self, hub_threshold: int = 0, hub_piece: int = 0):
-        """Degree-binned schedule (device workspace + host info), built once per structure."""
+    def schedule(self, hub_threshold: int = 0, hub_piece: int = 0, feat: Optional[int] = None, sweep: Optional[bool] = None):
+        """Degree-binned schedule (device workspace + host info), built once per structure.
+
+        With ``feat`` (the feature width about to be propagated) the L2-blocked sweep structure is
+        attached as well when the graph re-uses source rows enough for it to pay
+        (``sweep=None``: automatic; True / False force it)."""
         key = (hub_threshold, hub_piece)
+        lib = _lib.load()
         if self._sched is None or self._sched_key != key:
             assert self.device.type == "cuda", "schedules live on the GPU"
-            lib = _lib.load()
             n, nnz = self._sizes[0], self.nnz()
             with torch.cuda.device(self.device):
                 nbytes = lib.disco_schedule_workspace_bytes(n, nnz, hub_threshold, hub_piece)
@@ -207,7 +221,46 @@ class SparseTensor:
                 if keep < ws.numel() // 2:
                     ws = ws[:keep].clone()
             self._sched, self._sched_key = (ws, info), key
-        return self._sched
+            self._sweep = None
+        ws, info = self._sched
+        if feat is not None and sweep is not False:
+            window_rows = sweep_window_rows(feat)
+            built = getattr(self, "_sweep", None)
+            if built is None or built[0] != window_rows:
+                want = sweep if sweep is not None else self.sweep_pays()
+                self._sweep = (window_rows, None)
+                info.sweep_ws, info.sweep_windows = None, 0
+                if want and self._sizes[0] > 0:
+                    with torch.cuda.device(self.device):
+                        nb = lib.disco_sweep_workspace_bytes(info, self._sizes[1], window_rows)
+                        if nb:
+                            sw = torch.empty(int(nb), dtype=torch.uint8, device=self.device)
+                            rc = lib.disco_sweep_build(_lib.ptr(self._rowptr), _lib.ptr(self._col32), _lib.ptr(ws), info,
+                                                       self._sizes[1], window_rows, _lib.ptr(sw), sw.numel(),
+                                                       _lib.current_stream(self.device))
+                            if rc == -2:      # columns not sorted inside the rows: plain kernel stays in use
+                                sw = None
+                            else:
+                                _lib.check(rc, "disco_sweep_build")
+                            self._sweep = (window_rows, sw)
+        elif sweep is False:
+            info.sweep_ws, info.sweep_windows = None, 0
+            self._sweep = None
+        return ws, info
+
+    def sweep_pays(self) -> bool:
+        """The sweep kernel keeps ~64k rows in flight per GPU (256 CUs x 16 waves x 16 rows); it pays when
+        those rows together touch every source row several times per sweep."""
+        n, m = self._sizes
+        if n == 0 or m == 0:
+            return False
+        # Opt-in for now (DISCO_SWEEP=1): on MI355X the waves of one XCD do not yet stay inside one L2
+        # window at full Reddit scale (L2 hit rate 21 %), so the plain kernel is still faster there.
+        import os
+        if os.environ.get("DISCO_SWEEP", "0") != "1":
+            return False
+        in_flight = min(n, 65536)
+        return in_flight * (self.nnz() / n) / m >= 4.0
 
     def __repr__(self) -> str:
         return f"SparseTensor(sizes={self._sizes}, nnz={self.nnz()}, has_value={self.has_value()}, device={self.device})"

@@ -58,6 +58,9 @@ typedef struct disco_schedule_info {
   int64_t off_perm, off_piece_row, off_piece_begin, off_piece_end, off_piece_slot;
   int64_t off_multi_row, off_multi_first;
   int64_t ws_bytes;
+  /* optional L2-blocked sweep structure, filled by disco_sweep_build (0 / NULL when absent) */
+  int64_t sweep_windows, sweep_window_rows, sweep_count_padded, sweep_n_cols;
+  const void* sweep_ws;    /* DEVICE pointer kept inside this host struct */
 } disco_schedule_info;
 
 int disco_abi_version(void);
@@ -76,6 +79,21 @@ size_t disco_schedule_workspace_bytes(int64_t n_rows, int64_t nnz, int64_t hub_t
 int disco_schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz,
                          int64_t hub_threshold, int64_t hub_piece, void* sched_ws,
                          size_t sched_ws_bytes, disco_schedule_info* info_host, void* stream);
+
+/* ---- L2-blocked sweep (optional, for graphs whose rows re-use source rows heavily) -----------
+ * Builds the window pointers the sweep kernel needs (see disco_spmm.hip: source rows are cut into
+ * windows of `window_rows` rows that fit the XCD's 4 MiB L2; all resident waves walk the windows
+ * together with their row sums in registers).  Requires column indices sorted inside every row;
+ * returns DISCO_EUNSUPPORTED (and leaves the schedule without a sweep) when they are not.
+ * Once attached to `info_host`, disco_spmm_csr_f32 / disco_khop_csr_f32 use the sweep kernel for
+ * sum / mean reductions on 16-byte aligned operands; results have the same bits as without it.
+ * The caller keeps `sweep_ws` alive as long as `info_host` is used.  SYNCHRONISES `stream` once.
+ * No counterpart in the reference. */
+size_t disco_sweep_workspace_bytes(const disco_schedule_info* info_host, int64_t n_cols,
+                                   int64_t window_rows);
+int disco_sweep_build(const int64_t* rowptr, const int32_t* col, const void* sched_ws,
+                      disco_schedule_info* info_host, int64_t n_cols, int64_t window_rows,
+                      void* sweep_ws, size_t sweep_ws_bytes, void* stream);
 
 /* ---- SpMM -------------------------------------------------------------------------------
  * y[r, 0:F] = reduce_{e in row r} val[e] * x[col[e], 0:F]

@@ -204,3 +204,44 @@ def test_full_size_properties_arxiv_shaped():
     idx = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in rows])
     y64, bound = c_oracle.spmm_csr_f64acc(sub_rp, c[idx], v[idx], xs, want_bound=True)
     assert_fwd_close(y1[rows], y64, bound, what="arxiv-shaped sample")
+
+
+@pytest.mark.parametrize("F", [64, 128, 602])
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_sweep_kernel_same_bits_as_plain(F, reduce):
+    """The L2-blocked sweep kernel visits each row's entries in CSR order: same bits as the plain kernel
+    on the rows it owns (all rows below the hub threshold)."""
+    from disco_amd import _lib, ops
+    n = 5000
+    rowptr, col, val = random_csr(n, n, 60, seed=31, hubs=[(0, 5000), (7, 2100)], weighted=True)
+    x = np.random.default_rng(8).standard_normal((n, F)).astype(np.float32)
+    ld = (F + 31) // 32 * 32
+    xb = torch.zeros((n, ld), device=dev())
+    xb[:, :F] = torch.from_numpy(x).to(dev())
+    xd = xb[:, :F]
+    adj = to_adj(rowptr, col, val, n)
+    ws, info = adj.schedule(feat=F, sweep=False)
+    assert not info.sweep_ws
+    y_plain = ops.spmm_raw(adj, xd, reduce, out=torch.empty((n, ld), device=dev())[:, :F]).cpu().numpy()
+    adj2 = to_adj(rowptr, col, val, n)
+    ws2, info2 = adj2.schedule(feat=F, sweep=True)
+    assert info2.sweep_ws and info2.sweep_windows >= 1
+    y_sweep = ops.spmm_raw(adj2, xd, reduce, out=torch.empty((n, ld), device=dev())[:, :F]).cpu().numpy()
+    assert np.array_equal(y_plain, y_sweep)
+    y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x, want_bound=True)
+    if reduce == "mean":
+        cnt = np.maximum(np.diff(rowptr), 1)[:, None].astype(np.float64)
+        y64, bound = y64 / cnt, bound / cnt
+    assert_fwd_close(y_sweep, y64, bound, what=f"sweep {reduce} F={F}")
+
+
+def test_sweep_refuses_unsorted_columns():
+    from disco_amd import ops
+    rowptr, col, val = random_csr(300, 300, 20, seed=3, weighted=True, sort_cols=False)
+    adj = to_adj(rowptr, col, val, 300)
+    ws, info = adj.schedule(feat=128, sweep=True)
+    assert not info.sweep_ws                       # plain kernel stays in use
+    x = np.random.default_rng(1).standard_normal((300, 128)).astype(np.float32)
+    y = ops.spmm_raw(adj, torch.from_numpy(x).to(dev()), "sum").cpu().numpy()
+    y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x, want_bound=True)
+    assert_fwd_close(y, y64, bound)

@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--skew", type=float, default=None)
     ap.add_argument("--hub", default="0:0", help="comma list of threshold:piece")
+    ap.add_argument("--sweep", default="0", help="comma list of 0/1: use the L2-blocked sweep kernel")
+    ap.add_argument("--window-kb", default="2048", help="comma list: L2 window size in KiB (sweep)")
+    ap.add_argument("--bpc", default="4", help="comma list: sweep blocks per CU")
     ap.add_argument("--ncols", type=int, default=0, help="gather from a table of this many rows (rectangular, unnormalised)")
     args = ap.parse_args()
 
@@ -66,7 +69,11 @@ def main():
                     for force in args.force.split(","):
                         for mv in [int(v) for v in args.maxvec.split(",")]:
                             for s in [int(v) for v in args.slices.split(",")]:
-                                variants.append(dict(ld=ld, lib=libname, order=order, hub=hub, force=force, maxvec=mv, slices=s))
+                                for sw in [int(v) for v in args.sweep.split(",")]:
+                                    for wkb in ([int(v) for v in args.window_kb.split(",")] if sw else [0]):
+                                        for bpc in ([int(v) for v in args.bpc.split(",")] if sw else [0]):
+                                            variants.append(dict(ld=ld, lib=libname, order=order, hub=hub, force=force, maxvec=mv,
+                                                                 slices=s, sweep=sw, wkb=wkb, bpc=bpc))
 
     bufs = {}
     scheds = {}
@@ -82,7 +89,7 @@ def main():
                 bufs[ld] = (x, y)
             x, y = bufs[ld]
             thr, piece = (int(t) for t in v["hub"].split(":"))
-            key = (v["lib"], v["order"], thr, piece)
+            key = (v["lib"], v["order"], thr, piece, v["sweep"], v["wkb"])
             if key not in scheds:
                 nb = lib.disco_schedule_workspace_bytes(n, nnz, thr, piece)
                 ws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
@@ -92,8 +99,19 @@ def main():
                                                     ws.data_ptr(), ws.numel(), info, stream), "schedule")
                 sb = lib.disco_spmm_workspace_bytes(info, F)
                 sws = torch.empty(max(int(sb), 16), dtype=torch.uint8, device=dev)
-                scheds[key] = (ws, info, sws)
-            ws, info, sws = scheds[key]
+                swp = None
+                if v["sweep"]:
+                    nblk = (F + 255) // 256
+                    blk = ((F + nblk - 1) // nblk + 31) // 32 * 32
+                    wrows = max(64, v["wkb"] * 1024 // (4 * blk))
+                    nbs = lib.disco_sweep_workspace_bytes(info, adj.size(1), wrows)
+                    swp = torch.empty(int(nbs), dtype=torch.uint8, device=dev)
+                    _lib.check(lib.disco_sweep_build(adj._rowptr.data_ptr(), adj._col32.data_ptr(), ws.data_ptr(), info, adj.size(1),
+                                                     wrows, swp.data_ptr(), swp.numel(), stream), "sweep_build")
+                    print("sweep:", {"windows": info.sweep_windows, "window_rows": info.sweep_window_rows, "MB": swp.numel() >> 20}, flush=True)
+                scheds[key] = (ws, info, sws, swp)
+            ws, info, sws, swp = scheds[key]
+            lib.disco_set_tuning(b"sweep_blocks_per_cu", v["bpc"])
             if v["force"] == "auto":
                 lib.disco_set_tuning(b"force_g", 0)
                 lib.disco_set_tuning(b"force_nv", 0)
