@@ -51,14 +51,17 @@ _SIGNATURES = {
     "disco_inv_sqrt_f32": (c_int, [c_void_p, c_int64, c_void_p]),
     "disco_gcn_norm_coo_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "disco_pairscore_workspace_bytes": (c_size_t, [c_int64, c_int64]),
-    "disco_pairscore_prepare_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64] + [c_void_p] * 14 + [C.c_float, c_void_p, c_size_t, c_void_p]),
-    "disco_pairscore_logits_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
-    "disco_pairscore_edges_f32": (c_int, [c_void_p, c_int64, C.c_float, c_int, c_void_p, c_void_p, c_void_p, c_int64,
-                                          c_void_p, c_void_p]),
+    "disco_pairscore_prepare_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64] + [c_void_p] * 14 +
+                                    [C.c_float, c_void_p, c_size_t, c_void_p]),
+    "disco_pairscore_block_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64,
+                                          c_int, c_void_p]),
+    "disco_sym_threshold_count": (c_int, [c_void_p, c_int64, c_int64, C.c_float, c_int, c_void_p, c_void_p]),
+    "disco_sym_threshold_fill": (c_int, [c_void_p, c_int64, c_int64, C.c_float, c_int, c_void_p, c_int64, c_void_p, c_void_p,
+                                         c_void_p]),
 }
 
 # symbols that may legitimately be absent from an older build (none at the moment)
-_OPTIONAL = {n for n in _SIGNATURES if n.startswith('disco_pairscore')}
+_OPTIONAL = set()
 
 
 def exported_symbols():

@@ -1,0 +1,363 @@
+// disco_scorer.hip -- PGE_Edge pair scorer over all condensed-node pairs (gfx950, fp32 MFMA).
+//
+// Replaces the pair loop of edge_construction():
+//   for i in range(n): adj_syn[i] = pge_edge.inference(cat([Z[[i]*n], Z[arange(n)]], 1))
+//   (/root/reference/LargeScaleCondensing.py:304-305; model: /root/reference/models/parametrized_adj_lp.py:29-38)
+// and the symmetrise / threshold / nonzero post-processing (LargeScaleCondensing.py:306-310,
+// LargeScaleCondensing_induct.py:300-304, LargeScaleCondensing_Sampled.py:271-285).
+//
+// Factorisation (eval-mode BatchNorm folded, s = gamma / sqrt(var + eps), t = beta - mean * s):
+//   layer 1  h1[i,j,:] = relu(U[i,:] + V[j,:]),  U = s1 * (Z W1a^T),  V = s1 * (Z W1b^T + b1) + t1
+//            (the concatenation [z_i || z_j] splits W1 = [W1a | W1b]: two n x H GEMMs instead of n^2)
+//   layer 2  h2 = relu(W2' h1 + b2'),  W2' = diag(s2) W2,  b2' = s2 * b2 + t2      <- the only n^2 GEMM
+//   layer 3  logit = w3 . h2 + b3;  S = sigmoid(logit)
+// Layer 2 is a true [n^2, H] x [H, H] GEMM and runs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32:
+// bit-for-bit an fmaf chain, no reduced-precision path) because edges are kept where the symmetrised
+// sigmoid exceeds 0.99..0.9999 and small logit errors would flip them.  h1 is generated on the fly into
+// LDS, W2' lives in registers (each of the 8 waves of a workgroup owns 32 output features), the layer-3
+// dot product and the sigmoid are fused into the epilogue: nothing but S is written.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "disco_internal.h"
+
+namespace disco {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4s __attribute__((ext_vector_type(4)));
+
+struct ScorerWs {  // layout of the scorer workspace (all float32)
+  int64_t off_u, off_v, off_w2, off_b2, off_w3, off_b3, total;
+};
+
+static ScorerWs scorer_layout(int64_t n, int64_t H) {
+  ScorerWs L;
+  int64_t o = 0;
+  auto take = [&](int64_t floats) { int64_t at = o; o = (o + floats * 4 + 255) / 256 * 256; return at; };
+  L.off_u = take(n * H);
+  L.off_v = take(n * H);
+  L.off_w2 = take(H * H);
+  L.off_b2 = take(H);
+  L.off_w3 = take(H);
+  L.off_b3 = take(64);
+  L.total = o;
+  return L;
+}
+
+// ---- prepare: U, V (float32 dot products in k order), folded W2', b2', w3, b3 ----------------------
+// one thread per (node, hidden unit); D is small (<= a few hundred): Z row and W1 row are L1/L2 hits.
+__global__ __launch_bounds__(256) void k_scorer_uv(const float* __restrict__ Z, int64_t n, int64_t D, int64_t ldz,
+                                                   const float* __restrict__ W1, const float* __restrict__ b1,
+                                                   const float* __restrict__ g1, const float* __restrict__ be1,
+                                                   const float* __restrict__ m1, const float* __restrict__ v1, float eps,
+                                                   int H, float* __restrict__ U, float* __restrict__ V) {
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * H) return;
+  const int64_t i = idx / H;
+  const int h = (int)(idx % H);
+  const float* z = Z + i * ldz;
+  const float* wa = W1 + (int64_t)h * 2 * D;
+  const float* wb = wa + D;
+  float su = 0.0f, sv = 0.0f;
+  for (int64_t k = 0; k < D; ++k) {
+    const float zk = z[k];
+    su = fmaf(zk, wa[k], su);
+    sv = fmaf(zk, wb[k], sv);
+  }
+  const float s = g1[h] / sqrtf(v1[h] + eps);
+  const float t = be1[h] - m1[h] * s;
+  U[idx] = s * su;
+  V[idx] = s * (sv + b1[h]) + t;
+}
+
+__global__ __launch_bounds__(256) void k_scorer_fold(const float* __restrict__ W2, const float* __restrict__ b2,
+                                                     const float* __restrict__ g2, const float* __restrict__ be2,
+                                                     const float* __restrict__ m2, const float* __restrict__ v2,
+                                                     const float* __restrict__ W3, const float* __restrict__ b3, float eps, int H,
+                                                     float* __restrict__ W2f, float* __restrict__ b2f, float* __restrict__ w3,
+                                                     float* __restrict__ b3o) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < H * H) {
+    const int o = idx / H;
+    const float s = g2[o] / sqrtf(v2[o] + eps);
+    W2f[idx] = s * W2[idx];
+  }
+  if (idx < H) {
+    const float s = g2[idx] / sqrtf(v2[idx] + eps);
+    b2f[idx] = s * b2[idx] + (be2[idx] - m2[idx] * s);
+    w3[idx] = W3[idx];
+  }
+  if (idx == 0) b3o[0] = b3[0];
+}
+
+// ---- the n^2 part --------------------------------------------------------------------------------------
+// Workgroup = 8 waves (512 threads); tile = one i and 64 consecutive j (64 pairs); wave w owns output
+// features [32w, 32w+32) of layer 2 (waves beyond H/32 idle for small H).
+// MFMA 32x32x2 f32: lane (r = l & 31, hh = l >> 5) feeds A[pair r][k] and B[k][feature r] with
+// k = hh * H/2 + m at step m (the k order of the fma chain is a free choice as long as A and B agree).
+// sum over the 32 lanes of a half (= 32 features) of w3 * relu(acc[g] + bias) for all 16 registers g at once:
+// butterfly transpose-reduce (8+4+2+1 exchanges), then one exchange with lane ^ 16.  Lane r returns the
+// total for register g = r & 15.
+__device__ __forceinline__ float reduce_features(const f32x16& acc, float bias, float w3v, int r) {
+  float v[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) v[g] = w3v * fmaxf(acc[g] + bias, 0.0f);
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const int width = 8 >> step;
+    const bool upper = (r & width) != 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q < width) {
+        const float keep = upper ? v[q + width] : v[q];
+        const float send = upper ? v[q] : v[q + width];
+        v[q] = keep + __shfl_xor(send, width);
+      }
+    }
+  }
+  return v[0] + __shfl_xor(v[0], 16);
+}
+
+template <int H>
+__global__ __launch_bounds__(512) void k_scorer_pairs(const float* __restrict__ U, const float* __restrict__ V,
+                                                      const float* __restrict__ W2f, const float* __restrict__ b2f,
+                                                      const float* __restrict__ w3, const float* __restrict__ b3,
+                                                      int64_t i0, int64_t i1, int64_t j0, int64_t j1, float* __restrict__ out,
+                                                      int64_t ldo, int apply_sigmoid) {
+  constexpr int HH = H / 2;        // k values per lane half
+  constexpr int LDA = H + 4;       // padded LDS row (floats): conflict-free ds_read_b128
+  constexpr int NW = H / 32;       // waves with work
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* a_lds = lds;                       // [64][LDA]
+  float* red = lds + 64 * LDA;              // [8][64] per-wave partial logits
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const bool active = wave < NW;
+  // B fragments: W2'[feature 32*wave + r][hh*HH + m], m = 0..HH-1, kept in registers for the whole kernel
+  float breg[HH];
+  float bias = 0.0f, w3v = 0.0f;
+  if (active) {
+    const float* wrow = W2f + (int64_t)(32 * wave + r) * H + hh * HH;
+#pragma unroll
+    for (int m = 0; m < HH; m += 4) {
+      f4s t = *reinterpret_cast<const f4s*>(wrow + m);
+      breg[m] = t[0]; breg[m + 1] = t[1]; breg[m + 2] = t[2]; breg[m + 3] = t[3];
+    }
+    bias = b2f[32 * wave + r];
+    w3v = w3[32 * wave + r];
+  }
+  const float b3v = b3[0];
+  const int64_t nj = j1 - j0;
+  const int64_t jblocks = (nj + 63) / 64;
+  const int64_t tiles = (i1 - i0) * jblocks;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t i = i0 + t / jblocks;
+    const int64_t jb = j0 + (t % jblocks) * 64;
+    // ---- generate h1 tile: element e = tid + 512 q -> pair e / H, k = e % H -------------------------
+    {
+      constexpr int PER = 64 * H / 512;  // elements per thread
+      const int k = tid % H;
+      const float u = U[i * H + k];
+#pragma unroll 8
+      for (int q = 0; q < PER; ++q) {
+        const int p = (tid + 512 * q) / H;
+        int64_t j = jb + p;
+        j = j < j1 ? j : j1 - 1;
+        const float v = V[j * H + k];
+        a_lds[p * LDA + k] = fmaxf(u + v, 0.0f);
+      }
+    }
+    __syncthreads();
+    if (active) {
+      f32x16 acc0 = {0}, acc1 = {0};
+      const float* a0 = a_lds + r * LDA + hh * HH;
+      const float* a1 = a0 + 32 * LDA;
+      f4s x0 = *reinterpret_cast<const f4s*>(a0);
+      f4s x1 = *reinterpret_cast<const f4s*>(a1);
+#pragma unroll
+      for (int m = 0; m < HH; m += 4) {
+        // fragments of the next step are fetched while this step's 8 MFMAs issue; the scheduling barrier keeps
+        // the compiler from hoisting more LDS reads than that (register budget: 128 for W2', 32 accumulators)
+        f4s n0 = x0, n1 = x1;
+        if (m + 4 < HH) {
+          n0 = *reinterpret_cast<const f4s*>(a0 + m + 4);
+          n1 = *reinterpret_cast<const f4s*>(a1 + m + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[q], breg[m + q], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[q], breg[m + q], acc1, 0, 0, 0);
+        }
+        x0 = n0; x1 = n1;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // epilogue: h2 = relu(acc + b2'), partial logit = sum over this wave's 32 features of w3 * h2.
+      // acc register g of lane (r, hh) is pair row (g & 3) + 8 (g >> 2) + 4 hh, feature r.
+      const float s0 = reduce_features(acc0, bias, w3v, r);
+      const float s1 = reduce_features(acc1, bias, w3v, r);
+      const int g = r & 15;
+      const int prow = (g & 3) + 8 * (g >> 2) + 4 * hh;
+      if (r < 16) red[wave * 64 + prow] = s0;
+      else red[wave * 64 + 32 + prow] = s1;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float s = b3v;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[w * 64 + tid];
+      const int64_t j = jb + tid;
+      if (j < j1) {
+        if (apply_sigmoid) s = 1.0f / (1.0f + expf(-s));
+        out[(i - i0) * ldo + (j - j0)] = s;
+      }
+    }
+    // the next tile's generation may not overwrite a_lds / red before everybody is done reading
+    __syncthreads();
+  }
+}
+
+// ---- post-processing: symmetrise, threshold, diagonal, compaction ------------------------------------
+// variant 0 transductive: A = (S + S^T)/2; A[A < thr] = 0; diag = 1        (LargeScaleCondensing.py:306-308)
+// variant 1 inductive   : A = (S + S^T)/2; diag = 1; A[A < thr] = 0        (LargeScaleCondensing_induct.py:300-302)
+// variant 2 sampled     : off-diagonal as above (both directions averaged, thresholded, symmetric);
+//                         the n unit self-loops are APPENDED after the sorted edge list (_Sampled.py:271-285)
+__device__ __forceinline__ float sym_value(const float* __restrict__ S, int64_t lds, int64_t i, int64_t j, float thr,
+                                           int variant) {
+  if (i == j) {
+    if (variant == 2) return 0.0f;
+    if (variant == 1) return 1.0f < thr ? 0.0f : 1.0f;
+    return 1.0f;
+  }
+  const float a = (S[i * lds + j] + S[j * lds + i]) / 2.0f;
+  return a < thr ? 0.0f : a;
+}
+
+__global__ __launch_bounds__(256) void k_sym_count(const float* __restrict__ S, int64_t n, int64_t lds, float thr, int variant,
+                                                   int64_t* __restrict__ rowcount) {
+  const int64_t i = blockIdx.x;
+  int cnt = 0;
+  for (int64_t j = threadIdx.x; j < n; j += 256) cnt += sym_value(S, lds, i, j, thr, variant) != 0.0f;
+  __shared__ int part[256];
+  part[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rowcount[i] = part[0];
+}
+
+// one 64-lane wave per row keeps the columns in ascending order (torch.nonzero order)
+__global__ __launch_bounds__(64) void k_sym_fill(const float* __restrict__ S, int64_t n, int64_t lds, float thr, int variant,
+                                                 const int64_t* __restrict__ rowstart, int64_t E, int64_t* __restrict__ ei,
+                                                 float* __restrict__ ew) {
+  const int64_t i = blockIdx.x;
+  int64_t pos = rowstart[i];
+  const int lane = threadIdx.x;
+  for (int64_t jb = 0; jb < n; jb += 64) {
+    const int64_t j = jb + lane;
+    float a = 0.0f;
+    if (j < n) a = sym_value(S, lds, i, j, thr, variant);
+    const unsigned long long m = __ballot(a != 0.0f);
+    if (a != 0.0f) {
+      const int64_t p = pos + __popcll(m & ((1ull << lane) - 1ull));
+      ei[p] = i;
+      ei[E + p] = j;
+      ew[p] = a;
+    }
+    pos += __popcll(m);
+  }
+}
+
+}  // namespace disco
+
+using namespace disco;
+
+extern "C" size_t disco_pairscore_workspace_bytes(int64_t n, int64_t H) {
+  if (n < 0 || H <= 0) return 0;
+  return (size_t)scorer_layout(n, H).total;
+}
+
+extern "C" int disco_pairscore_prepare_f32(const float* Z, int64_t n, int64_t D, int64_t ldz, int64_t H, const float* W1,
+                                           const float* b1, const float* bn1_w, const float* bn1_b, const float* bn1_mean,
+                                           const float* bn1_var, const float* W2, const float* b2, const float* bn2_w,
+                                           const float* bn2_b, const float* bn2_mean, const float* bn2_var, const float* W3,
+                                           const float* b3, float eps, void* ws, size_t ws_bytes, void* stream_) {
+  if (n < 0 || D <= 0 || ldz < D) return DISCO_EINVAL;
+  if (H != 32 && H != 64 && H != 128 && H != 256) return DISCO_EUNSUPPORTED;
+  if (!Z || !W1 || !b1 || !bn1_w || !bn1_b || !bn1_mean || !bn1_var || !W2 || !b2 || !bn2_w || !bn2_b || !bn2_mean ||
+      !bn2_var || !W3 || !b3 || !ws)
+    return DISCO_EINVAL;
+  ScorerWs L = scorer_layout(n, H);
+  if ((size_t)L.total > ws_bytes) return DISCO_EWORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  char* w = static_cast<char*>(ws);
+  if (n > 0) {
+    hipLaunchKernelGGL(k_scorer_uv, dim3((unsigned)((n * H + 255) / 256)), dim3(256), 0, s, Z, n, D, ldz, W1, b1, bn1_w, bn1_b,
+                       bn1_mean, bn1_var, eps, (int)H, reinterpret_cast<float*>(w + L.off_u), reinterpret_cast<float*>(w + L.off_v));
+  }
+  hipLaunchKernelGGL(k_scorer_fold, dim3((unsigned)((H * H + 255) / 256)), dim3(256), 0, s, W2, b2, bn2_w, bn2_b, bn2_mean, bn2_var,
+                     W3, b3, eps, (int)H, reinterpret_cast<float*>(w + L.off_w2), reinterpret_cast<float*>(w + L.off_b2),
+                     reinterpret_cast<float*>(w + L.off_w3), reinterpret_cast<float*>(w + L.off_b3));
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}
+
+template <int H>
+static int launch_pairs(const char* w, const ScorerWs& L, int64_t i0, int64_t i1, int64_t j0, int64_t j1, float* out, int64_t ldo,
+                        int apply_sigmoid, hipStream_t s) {
+  const int64_t tiles = (i1 - i0) * ((j1 - j0 + 63) / 64);
+  int64_t blocks = tiles < 256 * 4 ? tiles : 256 * 4;
+  if (blocks < 1) return DISCO_OK;
+  const size_t lds_bytes = (size_t)(64 * (H + 4) + 8 * 64) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scorer_pairs<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
+  if (e != hipSuccess) { set_last_hip_error((int)e); return DISCO_EHIP; }
+  hipLaunchKernelGGL((k_scorer_pairs<H>), dim3((unsigned)blocks), dim3(512), lds_bytes, s,
+                     reinterpret_cast<const float*>(w + L.off_u), reinterpret_cast<const float*>(w + L.off_v),
+                     reinterpret_cast<const float*>(w + L.off_w2), reinterpret_cast<const float*>(w + L.off_b2),
+                     reinterpret_cast<const float*>(w + L.off_w3), reinterpret_cast<const float*>(w + L.off_b3), i0, i1, j0, j1, out,
+                     ldo, apply_sigmoid);
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}
+
+extern "C" int disco_pairscore_block_f32(const void* ws, int64_t n, int64_t H, int64_t i0, int64_t i1, int64_t j0, int64_t j1,
+                                         float* out, int64_t ldo, int apply_sigmoid, void* stream_) {
+  if (!ws || n < 0 || i0 < 0 || j0 < 0 || i1 > n || j1 > n || i1 < i0 || j1 < j0) return DISCO_EINVAL;
+  if (i1 == i0 || j1 == j0) return DISCO_OK;
+  if (!out || ldo < j1 - j0) return DISCO_EINVAL;
+  ScorerWs L = scorer_layout(n, H);
+  const char* w = static_cast<const char*>(ws);
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  switch (H) {
+    case 32: return launch_pairs<32>(w, L, i0, i1, j0, j1, out, ldo, apply_sigmoid, s);
+    case 64: return launch_pairs<64>(w, L, i0, i1, j0, j1, out, ldo, apply_sigmoid, s);
+    case 128: return launch_pairs<128>(w, L, i0, i1, j0, j1, out, ldo, apply_sigmoid, s);
+    case 256: return launch_pairs<256>(w, L, i0, i1, j0, j1, out, ldo, apply_sigmoid, s);
+    default: return DISCO_EUNSUPPORTED;
+  }
+}
+
+extern "C" int disco_sym_threshold_count(const float* S, int64_t n, int64_t lds, float threshold, int variant, int64_t* rowcount,
+                                         void* stream_) {
+  if (n < 0 || variant < 0 || variant > 2) return DISCO_EINVAL;
+  if (n == 0) return DISCO_OK;
+  if (!S || !rowcount || lds < n) return DISCO_EINVAL;
+  hipLaunchKernelGGL(k_sym_count, dim3((unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream_), S, n, lds, threshold, variant,
+                     rowcount);
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}
+
+extern "C" int disco_sym_threshold_fill(const float* S, int64_t n, int64_t lds, float threshold, int variant,
+                                        const int64_t* rowstart, int64_t E, int64_t* edge_index, float* edge_weight, void* stream_) {
+  if (n < 0 || E < 0 || variant < 0 || variant > 2) return DISCO_EINVAL;
+  if (n == 0 || E == 0) return DISCO_OK;
+  if (!S || !rowstart || !edge_index || !edge_weight || lds < n) return DISCO_EINVAL;
+  hipLaunchKernelGGL(k_sym_fill, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream_), S, n, lds, threshold, variant,
+                     rowstart, E, edge_index, edge_weight);
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}

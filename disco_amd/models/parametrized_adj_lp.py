@@ -1,0 +1,136 @@
+"""PGE_Edge with the reference's interface and state_dict keys
+(/root/reference/models/parametrized_adj_lp.py:11-52) plus the HIP pair scorer.
+
+``forward`` / ``inference`` on explicit pair embeddings keep the reference's behaviour with stock torch
+layers (training needs autograd on a small dense MLP: out of the accelerated path, SURVEY.md section 2
+row 13).  What the reference spends its time on -- scoring ALL n^2 pairs of condensed nodes in a Python
+loop (LargeScaleCondensing.py:304-305) and post-processing the n x n matrix -- is ``score_all_pairs``
+and ``edge_construction`` here, computed by libdisco_hip.so (fp32 MFMA for the 256 x 256 layer).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+
+_VARIANTS = {"transductive": 0, "inductive": 1, "sampled": 2}
+
+
+class PGE_Edge(nn.Module):
+
+    def __init__(self, nfeat, nhid=256, nlayers=3, device=None, args=None):
+        super(PGE_Edge, self).__init__()
+        self.layers = nn.ModuleList([])
+        self.layers.append(nn.Linear(nfeat * 2, nhid))
+        self.bns = torch.nn.ModuleList()
+        self.bns.append(nn.BatchNorm1d(nhid))
+        for i in range(nlayers - 2):
+            self.layers.append(nn.Linear(nhid, nhid))
+            self.bns.append(nn.BatchNorm1d(nhid))
+        self.layers.append(nn.Linear(nhid, 1))
+        self.device = device
+        self.reset_parameters()
+        self.cnt = 0
+        self.args = args
+
+    def forward(self, edge_embed, inference=False):
+        for ix, layer in enumerate(self.layers):
+            edge_embed = layer(edge_embed)
+            if ix != len(self.layers) - 1:
+                edge_embed = self.bns[ix](edge_embed)
+                edge_embed = F.relu(edge_embed)
+        pred = torch.sigmoid(edge_embed).reshape(-1)
+        return pred
+
+    @torch.no_grad()
+    def inference(self, edge_embed):
+        self.eval()
+        pred = self.forward(edge_embed, inference=True)
+        return pred
+
+    def reset_parameters(self):
+        def weight_reset(m):
+            if isinstance(m, nn.Linear):
+                m.reset_parameters()
+            if isinstance(m, nn.BatchNorm1d):
+                m.reset_parameters()
+        self.apply(weight_reset)
+
+    # ---- HIP path -------------------------------------------------------------------------------
+    def _prepare(self, Z: torch.Tensor):
+        if len(self.layers) != 3:
+            raise NotImplementedError("the HIP scorer implements the 3-layer PGE_Edge every driver instantiates")
+        if Z.device.type != "cuda":
+            raise RuntimeError("PGE_Edge.score_all_pairs runs on the GPU only; there is no CPU fallback")
+        if Z.dtype != torch.float32 or Z.dim() != 2:
+            raise TypeError("Z must be float32 [n, nfeat]")
+        Z = Z.contiguous() if Z.stride(1) != 1 else Z
+        n, D = Z.shape
+        H = self.layers[0].out_features
+        if self.layers[0].in_features != 2 * D:
+            raise ValueError(f"Z has {D} features but the scorer was built for nfeat={self.layers[0].in_features // 2}")
+        lib = _lib.load()
+        f32 = lambda t: t.detach().to(device=Z.device, dtype=torch.float32).contiguous()  # noqa: E731
+        p = [f32(self.layers[0].weight), f32(self.layers[0].bias), f32(self.bns[0].weight), f32(self.bns[0].bias),
+             f32(self.bns[0].running_mean), f32(self.bns[0].running_var), f32(self.layers[1].weight), f32(self.layers[1].bias),
+             f32(self.bns[1].weight), f32(self.bns[1].bias), f32(self.bns[1].running_mean), f32(self.bns[1].running_var),
+             f32(self.layers[2].weight), f32(self.layers[2].bias)]
+        with torch.cuda.device(Z.device):
+            nb = lib.disco_pairscore_workspace_bytes(n, H)
+            ws = torch.empty(max(int(nb), 256), dtype=torch.uint8, device=Z.device)
+            _lib.check(lib.disco_pairscore_prepare_f32(_lib.ptr(Z), n, D, Z.stride(0), H, *[_lib.ptr(t) for t in p],
+                                                       float(self.bns[0].eps), _lib.ptr(ws), ws.numel(),
+                                                       _lib.current_stream(Z.device)), "disco_pairscore_prepare_f32")
+        return ws, n, H, p
+
+    @torch.no_grad()
+    def score_block(self, Z: torch.Tensor, rows: Tuple[int, int], cols: Optional[Tuple[int, int]] = None, logits: bool = False,
+                    out: Optional[torch.Tensor] = None, _prepared=None) -> torch.Tensor:
+        """S[i, j] = inference([z_i || z_j]) for i in rows, j in cols (eval-mode BatchNorm)."""
+        ws, n, H, keep = _prepared or self._prepare(Z)
+        i0, i1 = rows
+        j0, j1 = cols if cols is not None else (0, n)
+        if out is None:
+            out = torch.empty((i1 - i0, j1 - j0), dtype=torch.float32, device=Z.device)
+        lib = _lib.load()
+        with torch.cuda.device(Z.device):
+            _lib.check(lib.disco_pairscore_block_f32(_lib.ptr(ws), n, H, i0, i1, j0, j1, _lib.ptr(out), out.stride(0),
+                                                     0 if logits else 1, _lib.current_stream(Z.device)), "disco_pairscore_block_f32")
+        return out
+
+    @torch.no_grad()
+    def score_all_pairs(self, Z: torch.Tensor, logits: bool = False) -> torch.Tensor:
+        """The full n x n score matrix of LargeScaleCondensing.py:304-305 (stays on the GPU)."""
+        return self.score_block(Z, (0, Z.shape[0]), None, logits)
+
+    @torch.no_grad()
+    def edge_construction(self, Z: torch.Tensor, threshold: float, variant: str = "transductive"):
+        """(edge_index int64 [2, E], edge_weight float32 [E]) of the condensed graph, on the GPU:
+        scores -> (S + S^T)/2 -> threshold / unit diagonal in the order of `variant` -> nonzero."""
+        v = _VARIANTS[variant]
+        S = self.score_all_pairs(Z)
+        n = S.shape[0]
+        lib = _lib.load()
+        dev = Z.device
+        with torch.cuda.device(dev):
+            s = _lib.current_stream(dev)
+            cnt = torch.empty(n, dtype=torch.int64, device=dev)
+            _lib.check(lib.disco_sym_threshold_count(_lib.ptr(S), n, S.stride(0), float(threshold), v, _lib.ptr(cnt), s),
+                       "disco_sym_threshold_count")
+            start = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(cnt, 0, out=start[1:])
+            E = int(start[-1])
+            ei = torch.empty((2, E), dtype=torch.int64, device=dev)
+            ew = torch.empty(E, dtype=torch.float32, device=dev)
+            _lib.check(lib.disco_sym_threshold_fill(_lib.ptr(S), n, S.stride(0), float(threshold), v, _lib.ptr(start), E,
+                                                    _lib.ptr(ei), _lib.ptr(ew), s), "disco_sym_threshold_fill")
+        if variant == "sampled":
+            # add_self_loops(edge_index, edge_weight, num_nodes=n): n unit loops appended (_Sampled.py:285)
+            loops = torch.arange(n, device=dev)
+            ei = torch.cat([ei, torch.stack([loops, loops])], dim=1)
+            ew = torch.cat([ew, torch.ones(n, device=dev)])
+        return ei, ew

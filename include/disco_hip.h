@@ -165,6 +165,42 @@ int disco_inv_sqrt_f32(float* deg, int64_t N, void* stream);
 int disco_gcn_norm_coo_apply_f32(const int64_t* row, const int64_t* col, const float* w_in,
                                  int64_t E, const float* dis, float* w_out, void* stream);
 
+/* ---- pair scorer (PGE_Edge over all pairs of condensed nodes) -------------------------------
+ * Replaces the loop `for i in range(n): adj_syn[i] = pge_edge.inference(cat([Z[[i]*n], Z], 1))`
+ * (/root/reference/LargeScaleCondensing.py:304-305) for the 3-layer model of
+ * /root/reference/models/parametrized_adj_lp.py:13-38 in eval mode (BatchNorm running statistics).
+ * prepare: folds BatchNorm into the layers and computes the two n x H first-layer factors
+ *          (W1 is [H, 2*D] row-major as nn.Linear stores it; H in {32, 64, 128, 256}).
+ * block  : out[i - i0, j - j0] = score([z_i || z_j]) for i in [i0, i1), j in [j0, j1);
+ *          apply_sigmoid = 0 returns the logit.  Layer 2 runs on the exact-fp32 MFMA. */
+size_t disco_pairscore_workspace_bytes(int64_t n, int64_t H);
+int disco_pairscore_prepare_f32(const float* Z, int64_t n, int64_t D, int64_t ldz, int64_t H,
+                                const float* W1, const float* b1, const float* bn1_weight,
+                                const float* bn1_bias, const float* bn1_mean, const float* bn1_var,
+                                const float* W2, const float* b2, const float* bn2_weight,
+                                const float* bn2_bias, const float* bn2_mean, const float* bn2_var,
+                                const float* W3, const float* b3, float eps, void* ws, size_t ws_bytes,
+                                void* stream);
+int disco_pairscore_block_f32(const void* ws, int64_t n, int64_t H, int64_t i0, int64_t i1, int64_t j0,
+                              int64_t j1, float* out, int64_t ldo, int apply_sigmoid, void* stream);
+
+/* Post-processing of the n x n score matrix S into a COO edge list in torch.nonzero (row-major) order.
+ * A = (S + S^T)/2, then
+ *   variant 0 (transductive, LargeScaleCondensing.py:306-308):  A[A<thr]=0; diag=1
+ *   variant 1 (inductive, LargeScaleCondensing_induct.py:300-302): diag=1; A[A<thr]=0
+ *   variant 2 (sampled, LargeScaleCondensing_Sampled.py:271-284): off-diagonal part only (the caller
+ *             appends the n unit self-loops, as add_self_loops does at :285).
+ * count writes the number of kept entries per row; the caller turns it into exclusive row starts
+ * (and the total E) and calls fill with edge_index int64 [2, E] row-major and edge_weight [E]. */
+int disco_sym_threshold_count(const float* S, int64_t n, int64_t lds, float threshold, int variant,
+                              int64_t* rowcount, void* stream);
+int disco_sym_threshold_fill(const float* S, int64_t n, int64_t lds, float threshold, int variant,
+                             const int64_t* rowstart, int64_t E, int64_t* edge_index,
+                             float* edge_weight, void* stream);
+
+/* Benchmark / test knobs ("force_g", "force_nv", "max_vec", "no_sweep", "sweep_blocks_per_cu"). */
+int disco_set_tuning(const char* key, int64_t value);
+
 #ifdef __cplusplus
 }
 #endif
