@@ -83,7 +83,7 @@ def main():
     from disco_amd import SparseTensor, _lib, graphgen, ops, utils
     lib = _lib.load()
 
-    name = "reddit" if args.workload == "papers100M-shard" and False else args.workload
+    name = args.workload
     spec = graphgen.SPECS["papers100M" if name == "papers100M-shard" else name]
     n_local = spec.n_nodes if name != "papers100M-shard" else spec.n_nodes // 8
     nnz_target = spec.nnz if name != "papers100M-shard" else spec.nnz // 8
@@ -194,6 +194,17 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": round(tot_bytes / max(len(events), 1)),
                 "gather_model_GBs": round((sum((nnz * 8.0 + nnz * f * 4.0 + n_local * f * 4.0) for _, _, f in events))
                                           / (sum(durs_ms) * 1e-3) / 1e9, 1) if durs_ms else 0.0}
+
+    # HBM/fabric bytes per launch from the PMC passes committed under profiles/ (same command, same config);
+    # bench.py cannot read hardware counters itself.
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if world == 1 and name == "reddit" and n_slices == 3 and args.scale == 1.0 and not int(info.sweep_windows):
+            roofline["traffic"] = round(pmc["reddit_K2_slices3"]["traffic_bytes_per_launch"])
+            roofline["traffic_source"] = "profiles/r1/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 read correction)"
+    except (OSError, KeyError, ValueError):
+        pass
 
     value = units_per_step * args.steps / elapsed
     out = {

@@ -45,7 +45,6 @@ def _worker(rank, world, port, n, F, K, result_dir):
         rp = torch.from_numpy(rowptr[lo:hi + 1] - rowptr[lo])
         sl = slice(rowptr[lo], rowptr[hi])
         part = RowPartition(rp, torch.from_numpy(col[sl]), torch.from_numpy(val[sl]), offs, rank, world, spmm_fn=_oracle_spmm)
-        assert part.adj_int.nnz() + part.adj_halo.nnz() == hi - lo or True
         assert part.adj_int.nnz() + part.adj_halo.nnz() == rowptr[hi] - rowptr[lo]
         cur = torch.from_numpy(x[lo:hi].copy())
         for _ in range(K):
