@@ -1,0 +1,181 @@
+"""GPU tests of the reference-shaped module API (SGConv / GCNConv / SAGEConv / GINConv / MessagePassing /
+BasicGNN models): forward against the oracle, backward against a dense float64 autograd reference."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_fwd_close, csr_to_coo, orc, random_csr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_graph(n=400, avg=8, seed=1, weighted=True):
+    rowptr, col, val = random_csr(n, n, avg, seed=seed, hubs=[(3, 2500)], weighted=weighted)
+    if val is not None:
+        val = (np.abs(val) * 0.3 + 0.01).astype(np.float32)
+    return rowptr, col, val
+
+
+def to_adj(rowptr, col, val, n):
+    from disco_amd import SparseTensor
+    return SparseTensor(rowptr=torch.from_numpy(rowptr).to(DEV), col=torch.from_numpy(col).to(DEV),
+                        value=None if val is None else torch.from_numpy(val).to(DEV), sparse_sizes=(n, n), is_sorted=True)
+
+
+def dense(rowptr, col, val, n):
+    A = np.zeros((n, n))
+    r, c = csr_to_coo(rowptr, col)
+    np.add.at(A, (r, c), 1.0 if val is None else val.astype(np.float64))
+    return A
+
+
+def test_sgconv_adj_t_and_edge_index_paths():
+    from disco_amd.models.convs_large import SGConv
+    n, F, C, K = 400, 96, 7, 2
+    rowptr, col, val = make_graph(n)
+    x = np.random.default_rng(0).standard_normal((n, F)).astype(np.float32)
+    conv = SGConv(F, C, K=K).to(DEV)
+    W, b = conv.lin.weight.detach().cpu().numpy().astype(np.float64), conv.lin.bias.detach().cpu().numpy().astype(np.float64)
+    ref = orc.khop_csr(rowptr, col, val, x, K, np.float64) @ W.T + b
+    with torch.no_grad():
+        out = conv(torch.from_numpy(x).to(DEV), to_adj(rowptr, col, val, n)).cpu().numpy()
+    assert np.allclose(out, ref, rtol=2e-4, atol=2e-4)
+    # Tensor edge_index: out[col] += w * x[row]  <=>  CSR row r has entries (col -> source)
+    row_idx, _ = csr_to_coo(rowptr, col)
+    ei = torch.from_numpy(np.stack([col, row_idx])).to(DEV)          # source = CSR col, target = CSR row
+    with torch.no_grad():
+        out2 = conv(torch.from_numpy(x).to(DEV), ei, torch.from_numpy(val).to(DEV)).cpu().numpy()
+    assert np.allclose(out2, ref, rtol=2e-4, atol=2e-4)
+    assert conv._edge_cache.struct is not None
+    s1 = conv._edge_cache.struct
+    with torch.no_grad():
+        conv(torch.from_numpy(x).to(DEV), ei, torch.from_numpy(val).to(DEV))
+    assert conv._edge_cache.struct is s1                              # CSR built once per edge_index tensor
+
+
+def test_gcnconv_forward_backward_vs_dense_autograd():
+    from disco_amd.models.convs_large import GCNConv
+    n, F, C = 300, 40, 16
+    rowptr, col, val = make_graph(n, seed=2)
+    A = dense(rowptr, col, val, n)
+    x = np.random.default_rng(1).standard_normal((n, F)).astype(np.float32)
+    conv = GCNConv(F, C).to(DEV)
+    with torch.no_grad():
+        conv.bias.normal_()
+    xd = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    out = conv(xd, to_adj(rowptr, col, val, n))
+    g = torch.from_numpy(np.random.default_rng(2).standard_normal((n, C)).astype(np.float32)).to(DEV)
+    (out * g).sum().backward()
+    # dense float64 reference
+    At = torch.from_numpy(A)
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    Wr = conv.lin.weight.detach().cpu().double().requires_grad_(True)
+    br = conv.bias.detach().cpu().double().requires_grad_(True)
+    outr = At @ (xr @ Wr.T) + br
+    (outr * g.cpu().double()).sum().backward()
+    assert torch.allclose(out.detach().cpu().double(), outr.detach(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(xd.grad.cpu().double(), xr.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(conv.lin.weight.grad.cpu().double(), Wr.grad, rtol=1e-3, atol=1e-3)
+    assert torch.allclose(conv.bias.grad.cpu().double(), br.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("model_name", ["SGC", "GCN", "GraphSAGE", "GIN", "JKNet"])
+def test_models_train_step_on_condensed_graph(model_name):
+    """S2 of SURVEY.md: model.forward(feat_syn, edge_index_syn, edge_weight=edge_weight_syn), nll_loss,
+    backward (LargeScaleCondensing.py:334-339) -- against the same model evaluated on a dense adjacency."""
+    from disco_amd import utils
+    from disco_amd.models import basicgnn_large as M
+    torch.manual_seed(0)
+    n, d, C = 250, 32, 5
+    rng = np.random.default_rng(7)
+    E = 3000
+    ei = torch.from_numpy(rng.integers(0, n, (2, E))).to(DEV)
+    ew = torch.from_numpy(rng.random(E).astype(np.float32)).to(DEV)
+    if model_name in ("SGC", "GCN", "JKNet"):
+        ei, ew = utils.gcn_norm(ei, ew, n, add_self_loops=False)
+    kw = dict(nfeat=d, nhid=16, nclass=C, dropout=0.0, nlayers=2)
+    if model_name == "SGC":
+        model = M.SGC(sgc=True, **kw)
+    elif model_name == "JKNet":
+        model = M.JKNet(nfeat=d, nhid=16, nclass=C, dropout=0.0, nlayers=3, norm="BatchNorm", jk="cat")
+    else:
+        model = getattr(M, model_name)(norm="BatchNorm", **kw)
+    model = model.to(DEV)
+    model.initialize()
+    x = torch.randn(n, d, device=DEV, requires_grad=True)
+    y = torch.from_numpy(rng.integers(0, C, n)).to(DEV)
+    model.train()
+    out = model.forward(x, ei, edge_weight=ew)
+    loss = torch.nn.functional.nll_loss(out, y)
+    loss.backward()
+    assert out.shape == (n, C) and torch.isfinite(out).all() and torch.isfinite(x.grad).all()
+    # dense check of one propagation inside the model: A^T x with A[row, col] = w
+    A = torch.zeros(n, n, device=DEV, dtype=torch.float64).index_put_((ei[1], ei[0]), ew.double(), accumulate=True)
+    conv0 = model.convs[0]
+    reduce = getattr(conv0, "aggr", "add")
+    with torch.no_grad():
+        prop = conv0.propagate(ei, x=x.detach(), edge_weight=ew)
+        refp = A @ x.detach().double()
+        if reduce == "mean":
+            cnt = torch.zeros(n, device=DEV, dtype=torch.float64).index_add_(0, ei[1], torch.ones(E, device=DEV, dtype=torch.float64))
+            refp = refp / cnt.clamp(min=1)[:, None]
+    assert torch.allclose(prop.double(), refp, rtol=1e-4, atol=1e-4)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    opt.step()
+
+
+def test_predict_keeps_graph_resident_and_matches_dense():
+    from disco_amd.models import basicgnn_large as M
+    torch.manual_seed(1)
+    n, d, C = 500, 64, 6
+    rowptr, col, val = make_graph(n, seed=5)
+    adj = to_adj(rowptr, col, val, n)
+    x = torch.randn(n, d, device=DEV)
+    for model in (M.SGC(nfeat=d, nhid=32, nclass=C, nlayers=2, sgc=True), M.GCN(nfeat=d, nhid=32, nclass=C, nlayers=2, norm="BatchNorm")):
+        model = model.to(DEV)
+        model.initialize()
+        out = model.predict(x, adj.to(DEV))
+        assert adj.to(DEV) is adj                                   # .to(device) of a resident adjacency is a no-op
+        A = torch.from_numpy(dense(rowptr, col, val, n)).to(DEV)
+        model.eval()
+        with torch.no_grad():
+            if model.sgc:
+                h = (A @ (A @ x.double())).float()
+                ref = torch.log_softmax(model.convs[0].lin(h), dim=1)
+            else:
+                h = (A @ model.convs[0].lin(x).double()).float() + model.convs[0].bias
+                h = torch.relu(model.norms[0](h))
+                h = (A @ model.convs[1].lin(h).double()).float() + model.convs[1].bias
+                ref = torch.log_softmax(h, dim=1)
+        assert torch.allclose(out, ref, rtol=2e-4, atol=2e-4)
+        assert torch.equal(model.full_inference(x, adj), out)
+
+
+def test_max_message_passing_and_sampled_inference():
+    from disco_amd import SparseTensor
+    from disco_amd.models import basicgnn_large as M
+    from disco_amd.models.convs_large import MessagePassing
+    n, d = 300, 24
+    rowptr, col, val = make_graph(n, seed=9)
+    adj = to_adj(rowptr, col, val, n)
+    x = torch.randn(n, d, device=DEV)
+    aggr = MessagePassing(aggr="max")
+    t = aggr.propagate(adj, x=x)                                     # LargeScaleCondensing.py:172
+    ref = orc.max_aggregate(rowptr, col, x.cpu().numpy())
+    assert np.array_equal(t.cpu().numpy(), ref)
+    feat_transform = torch.concat((x, t), dim=1)                     # :173
+    assert feat_transform.shape == (n, 2 * d)
+    # bipartite batch as a NeighborSampler would hand it over: first 50 targets, all sources
+    class Batch:  # noqa: D401 - minimal stand-in for torch_geometric's EdgeIndex tuple
+        def __init__(self, adj_t):
+            self.adj_t = adj_t
+    rp = rowptr[:51]
+    sub = SparseTensor(rowptr=torch.from_numpy(rp.copy()).to(DEV), col=torch.from_numpy(col[:rp[-1]]).to(DEV),
+                       value=torch.from_numpy(val[:rp[-1]]).to(DEV), sparse_sizes=(50, n), is_sorted=True)
+    model = M.SGC(nfeat=d, nhid=8, nclass=3, nlayers=1, sgc=True).to(DEV)
+    loader = [(50, torch.arange(n), Batch(sub))]
+    out = model.inference(x.cpu(), loader, DEV)
+    with torch.no_grad():
+        full = model.predict(x, adj)
+    assert torch.allclose(out, full[:50], rtol=1e-4, atol=1e-5)
