@@ -139,7 +139,9 @@ extern "C" int disco_set_tuning(const char* key, int64_t value) {
   if (!strcmp(key, "force_g")) t.force_g = (int)value;
   else if (!strcmp(key, "force_nv")) t.force_nv = (int)value;
   else if (!strcmp(key, "max_vec")) t.max_vec = (int)value;
-  else if (!strcmp(key, "no_sweep")) t.no_sweep = (int)value;
+  else if (!strcmp(key, "sweep_mode")) t.sweep_mode = (int)value;
+  else if (!strcmp(key, "win_cols")) t.win_cols = (int)value;
+  else if (!strcmp(key, "win_rpg")) t.win_rows_per_group = (int)value;
   else if (!strcmp(key, "sweep_blocks_per_cu")) t.sweep_blocks_per_cu = (int)value;
   else return DISCO_EINVAL;
   return DISCO_OK;

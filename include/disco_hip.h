@@ -198,7 +198,7 @@ int disco_sym_threshold_fill(const float* S, int64_t n, int64_t lds, float thres
                              const int64_t* rowstart, int64_t E, int64_t* edge_index,
                              float* edge_weight, void* stream);
 
-/* Benchmark / test knobs ("force_g", "force_nv", "max_vec", "no_sweep", "sweep_blocks_per_cu"). */
+/* Benchmark / test knobs ("force_g", "force_nv", "max_vec", "sweep_mode", "win_cols", "sweep_blocks_per_cu"). */
 int disco_set_tuning(const char* key, int64_t value);
 
 #ifdef __cplusplus

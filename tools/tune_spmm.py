@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--sweep", default="0", help="comma list of 0/1: use the L2-blocked sweep kernel")
     ap.add_argument("--window-kb", default="2048", help="comma list: L2 window size in KiB (sweep)")
     ap.add_argument("--bpc", default="4", help="comma list: sweep blocks per CU")
+    ap.add_argument("--mode", default="2", help="comma list: 1 = persistent sweep kernel, 2 = windowed launches")
+    ap.add_argument("--rpg", default="4", help="comma list: rows per lane group per windowed launch")
+    ap.add_argument("--wincols", default="128", help="comma list: column block width of the windowed launches")
     ap.add_argument("--ncols", type=int, default=0, help="gather from a table of this many rows (rectangular, unnormalised)")
     args = ap.parse_args()
 
@@ -72,8 +75,11 @@ def main():
                                 for sw in [int(v) for v in args.sweep.split(",")]:
                                     for wkb in ([int(v) for v in args.window_kb.split(",")] if sw else [0]):
                                         for bpc in ([int(v) for v in args.bpc.split(",")] if sw else [0]):
-                                            variants.append(dict(ld=ld, lib=libname, order=order, hub=hub, force=force, maxvec=mv,
-                                                                 slices=s, sweep=sw, wkb=wkb, bpc=bpc))
+                                            for mode in ([int(v) for v in args.mode.split(",")] if sw else [0]):
+                                                for wc in ([int(v) for v in args.wincols.split(",")] if sw and mode == 2 else [0]):
+                                                    for rpg in ([int(v) for v in args.rpg.split(",")] if sw and mode == 2 else [0]):
+                                                        variants.append(dict(ld=ld, lib=libname, order=order, hub=hub, force=force, maxvec=mv,
+                                                                             slices=s, sweep=sw, wkb=wkb, bpc=bpc, mode=mode, wc=wc, rpg=rpg))
 
     bufs = {}
     scheds = {}
@@ -89,7 +95,7 @@ def main():
                 bufs[ld] = (x, y)
             x, y = bufs[ld]
             thr, piece = (int(t) for t in v["hub"].split(":"))
-            key = (v["lib"], v["order"], thr, piece, v["sweep"], v["wkb"])
+            key = (v["lib"], v["order"], thr, piece, v["sweep"], v["wkb"], v["mode"], v["wc"])
             if key not in scheds:
                 nb = lib.disco_schedule_workspace_bytes(n, nnz, thr, piece)
                 ws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
@@ -101,7 +107,8 @@ def main():
                 sws = torch.empty(max(int(sb), 16), dtype=torch.uint8, device=dev)
                 swp = None
                 if v["sweep"]:
-                    nblk = (F + 255) // 256
+                    cap = 256 if v["mode"] == 1 else v["wc"]
+                    nblk = (F + cap - 1) // cap
                     blk = ((F + nblk - 1) // nblk + 31) // 32 * 32
                     wrows = max(64, v["wkb"] * 1024 // (4 * blk))
                     nbs = lib.disco_sweep_workspace_bytes(info, adj.size(1), wrows)
@@ -112,6 +119,9 @@ def main():
                 scheds[key] = (ws, info, sws, swp)
             ws, info, sws, swp = scheds[key]
             lib.disco_set_tuning(b"sweep_blocks_per_cu", v["bpc"])
+            lib.disco_set_tuning(b"sweep_mode", v["mode"])
+            lib.disco_set_tuning(b"win_cols", v["wc"])
+            lib.disco_set_tuning(b"win_rpg", v["rpg"])
             if v["force"] == "auto":
                 lib.disco_set_tuning(b"force_g", 0)
                 lib.disco_set_tuning(b"force_nv", 0)
