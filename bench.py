@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--hub-threshold", type=int, default=0)
     ap.add_argument("--hub-piece", type=int, default=0)
     ap.add_argument("--skew", type=float, default=None)
+    ap.add_argument("--sweep", default="auto", choices=["auto", "on", "off"],
+                    help="L2-blocked windowed launches (auto: when the graph re-uses source rows enough)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; reported in config)")
     return ap.parse_args()
 
@@ -113,7 +115,10 @@ def main():
         tmp = torch.empty((n_local, ld), dtype=torch.float32, device=dev)[:, :F]
         n_slices = args.slices if args.slices > 0 else auto_slices(n_local, F)
         thr = -args.hub_threshold if args.natural_order and args.hub_threshold else (-2048 if args.natural_order else args.hub_threshold)
-        ws, info = adj.schedule(thr, args.hub_piece)
+        ws, info = adj.schedule(thr, args.hub_piece, feat=F, sweep={"auto": None, "on": True, "off": False}[args.sweep])
+        swept = bool(info.sweep_ws) and int(info.sweep_windows) > 0
+        if swept:
+            n_slices = 1      # the library cuts the columns into its own blocks (one C-ABI call per hop)
         sws_bytes = lib.disco_spmm_workspace_bytes(info, F)
         sws = torch.empty(max(int(sws_bytes), 16), dtype=torch.uint8, device=dev)
         per = (F + n_slices - 1) // n_slices
@@ -188,9 +193,12 @@ def main():
     tot_bytes = sum(algo_bytes(f) for _, _, f in events)
     avg_ms = sum(durs_ms) / max(len(durs_ms), 1)
     achieved = tot_bytes / (sum(durs_ms) * 1e-3) / 1e9 if durs_ms else 0.0
+    swept_now = world == 1 and bool(info.sweep_ws) and int(info.sweep_windows) > 0
+    kernel_name = ("k_spmm_rows_win: one timed call = one hop = %d window launches x column blocks of <= 128 floats"
+                   % int(info.sweep_windows)) if swept_now else "k_spmm_rows (+ k_spmm_hub, same C-ABI call)"
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernel": "k_spmm_rows", "launches_per_step": len(events) // max(args.steps, 1),
+                "kernel": kernel_name, "launches_per_step": len(events) // max(args.steps, 1),
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": round(tot_bytes / max(len(events), 1)),
                 "gather_model_GBs": round((sum((nnz * 8.0 + nnz * f * 4.0 + n_local * f * 4.0) for _, _, f in events))
                                           / (sum(durs_ms) * 1e-3) / 1e9, 1) if durs_ms else 0.0}
@@ -200,8 +208,9 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")) as fh:
             pmc = json.load(fh)
-        if world == 1 and name == "reddit" and n_slices == 3 and args.scale == 1.0 and not int(info.sweep_windows):
-            roofline["traffic"] = round(pmc["reddit_K2_slices3"]["traffic_bytes_per_launch"])
+        key = "reddit_K2_windowed" if swept_now else "reddit_K2_slices3"
+        if world == 1 and name == "reddit" and args.scale == 1.0 and (swept_now or n_slices == 3) and key in pmc:
+            roofline["traffic"] = round(pmc[key]["traffic_bytes_per_launch"])
             roofline["traffic_source"] = "profiles/r1/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 read correction)"
     except (OSError, KeyError, ValueError):
         pass
@@ -214,6 +223,7 @@ def main():
         "config": {"workload": f"{spec.name} K={K} GCN-normalised propagation, N={n_local}{'/rank' if world > 1 else ''}, "
                                f"nnz={nnz}{'/rank' if world > 1 else ''} (incl. self-loops), F={F}",
                    "K": K, "F": F, "nnz_per_rank": nnz, "rows_per_rank": n_local, "col_slices": n_slices, "ld": ld,
+                   "l2_windows": int(info.sweep_windows) if info.sweep_ws else 0,
                    "skew": skew, "parallelism": parallelism, "scale": args.scale,
                    "schedule": {"hub_rows": int(info.n_hub_rows), "hub_pieces": int(info.n_hub_pieces),
                                 "max_row_nnz": int(info.max_row_nnz)},

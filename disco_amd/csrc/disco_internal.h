@@ -15,7 +15,7 @@ struct Tuning {
   int max_vec = 0;    // 0 = 4
   int sweep_mode = 2; // with a sweep structure attached: 0 = ignore it, 1 = persistent sweep kernel, 2 = windowed launches
   int win_cols = 0;   // column block width of the windowed launches (0 = 128)
-  int win_rows_per_group = 0;  // consecutive rows one lane group handles per windowed launch (0 = 4)
+  int win_rows_per_group = 0;  // consecutive rows one lane group handles per windowed launch (0 = 1)
   int sweep_blocks_per_cu = 0;  // 0 = 4
 };
 

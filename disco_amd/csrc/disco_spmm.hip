@@ -534,7 +534,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       const disco_schedule_info& s = *a.info;
       const uint32_t* wptr = reinterpret_cast<const uint32_t*>(s.sweep_ws);
       const int P = (int)s.sweep_windows;
-      const int rpg = tuning().win_rows_per_group > 0 ? tuning().win_rows_per_group : 4;
+      const int rpg = tuning().win_rows_per_group > 0 ? tuning().win_rows_per_group : 1;
       int64_t blocks = (count + 4 * RPW * rpg - 1) / (4 * RPW * rpg);
       if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
       for (int w = 0; w < P; ++w) {

@@ -20,11 +20,14 @@ import torch
 from . import _lib
 
 
-def sweep_window_rows(feat: int, window_bytes: int = 2 << 20) -> int:
+WIN_COLS = 128           # column block width of the windowed launches (libdisco_hip default)
+WINDOW_BYTES = 6 << 20   # measured optimum on MI355X (4 MiB L2 per XCD): fewer, slightly over-sized windows win
+
+
+def sweep_window_rows(feat: int, window_bytes: int = WINDOW_BYTES, cap: int = WIN_COLS) -> int:
     """Source rows per L2 window for feature width `feat`: the kernels cut wide features into balanced
-    column blocks of at most 256 floats (multiples of 32) and one window of one block should take
-    ~2 MB of the XCD's 4 MiB L2."""
-    nblk = max(1, (feat + 255) // 256)
+    column blocks of at most `cap` floats (multiples of 32); one window of one block takes `window_bytes`."""
+    nblk = max(1, (feat + cap - 1) // cap)
     blk = max(32, ((feat + nblk - 1) // nblk + 31) // 32 * 32)
     return max(64, window_bytes // (4 * blk))
 
@@ -227,7 +230,7 @@ class SparseTensor:
             window_rows = sweep_window_rows(feat)
             built = getattr(self, "_sweep", None)
             if built is None or built[0] != window_rows:
-                want = sweep if sweep is not None else self.sweep_pays()
+                want = sweep if sweep is not None else self.sweep_pays(feat)
                 self._sweep = (window_rows, None)
                 info.sweep_ws, info.sweep_windows = None, 0
                 if want and self._sizes[0] > 0:
@@ -248,19 +251,20 @@ class SparseTensor:
             self._sweep = None
         return ws, info
 
-    def sweep_pays(self) -> bool:
-        """The sweep kernel keeps ~64k rows in flight per GPU (256 CUs x 16 waves x 16 rows); it pays when
-        those rows together touch every source row several times per sweep."""
-        n, m = self._sizes
-        if n == 0 or m == 0:
-            return False
-        # Opt-in for now (DISCO_SWEEP=1): on MI355X the waves of one XCD do not yet stay inside one L2
-        # window at full Reddit scale (L2 hit rate 21 %), so the plain kernel is still faster there.
+    def sweep_pays(self, feat: int = WIN_COLS) -> bool:
+        """L2-blocked (windowed) propagation re-reads and re-writes the output block once per window, so it
+        pays when a row has many entries per window: mean row length >= 8 x number of windows.
+        (Reddit: 492 entries/row, 19 windows -> yes; products / arxiv / papers100M -> no.)
+        DISCO_SWEEP=0 disables it, DISCO_SWEEP=1 forces it."""
         import os
-        if os.environ.get("DISCO_SWEEP", "0") != "1":
+        env = os.environ.get("DISCO_SWEEP")
+        if env is not None:
+            return env == "1"
+        n, m = self._sizes
+        if n == 0 or m == 0 or self.nnz() >= 2 ** 32 - 1:
             return False
-        in_flight = min(n, 65536)
-        return in_flight * (self.nnz() / n) / m >= 4.0
+        windows = (m + sweep_window_rows(feat) - 1) // sweep_window_rows(feat)
+        return self.nnz() / n >= 8.0 * windows
 
     def __repr__(self) -> str:
         return f"SparseTensor(sizes={self._sizes}, nnz={self.nnz()}, has_value={self.has_value()}, device={self.device})"
