@@ -96,6 +96,67 @@ template <int VEC, int OP> __device__ __forceinline__ void vcombine(typename Vec
   }
 }
 
+// Lane offsets of the NV vectors a lane owns.  Lanes past the row's last vector re-read the last valid
+// vector (no branch in the load stream); their accumulators are never stored.
+template <int VEC, int G, int NV>
+__device__ __forceinline__ void lane_offsets(int nvec, int gl, int64_t (&off)[NV]) {
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    int idx = gl + G * v;
+    idx = idx < nvec ? idx : nvec - 1;
+    off[v] = (int64_t)idx * VEC;
+  }
+}
+
+// Consume one cooperative batch: lane j of the group holds entry j (column cv, value wv), n <= G valid.
+template <int VEC, int G, int NV, int OP, bool HASVAL>
+__device__ __forceinline__ void consume_batch(int cv, float wv, int n, const float* __restrict__ x, int64_t ldx,
+                                              const int64_t (&off)[NV], typename Vec<VEC>::type (&acc)[NV]) {
+  typedef typename Vec<VEC>::type V;
+  constexpr int U = Unroll<NV>::value;
+  int j = 0;
+  for (; j + U <= n; j += U) {
+    V xr[U][NV];
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int c = bcast_i<G>(cv, j + u);
+      w[u] = HASVAL ? bcast_f<G>(wv, j + u) : 1.0f;
+      const float* rp = x + (int64_t)c * ldx;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) xr[u][v] = *reinterpret_cast<const V*>(rp + off[v]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) vupdate<VEC, OP, HASVAL>(acc[v], w[u], xr[u][v]);
+    }
+  }
+  if (j < n) {
+    // remainder (< U entries): one more full-depth batch instead of a serial tail.  Slots past the
+    // end re-read the last valid neighbour row (a cache hit) and are dropped by a select, never by
+    // a multiply with 0 (0 * inf would poison the sum).
+    V xr[U][NV];
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ju = j + u < n ? j + u : n - 1;
+      int c = bcast_i<G>(cv, ju);
+      w[u] = HASVAL ? bcast_f<G>(wv, ju) : 1.0f;
+      const float* rp = x + (int64_t)c * ldx;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) xr[u][v] = *reinterpret_cast<const V*>(rp + off[v]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (j + u < n) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) vupdate<VEC, OP, HASVAL>(acc[v], w[u], xr[u][v]);
+      }
+    }
+  }
+}
+
 // Accumulate entries [beg, end) of one CSR row into acc[NV].  All lanes of the group call this
 // with the same (beg, end); lane `gl` owns vectors gl + G*v.
 template <int VEC, int G, int NV, int OP, bool HASVAL>
@@ -103,17 +164,8 @@ __device__ __forceinline__ void accumulate_range(int64_t beg, int64_t end, const
                                                  const float* __restrict__ val, const float* __restrict__ x,
                                                  int64_t ldx, int nvec, int gl,
                                                  typename Vec<VEC>::type (&acc)[NV]) {
-  typedef typename Vec<VEC>::type V;
-  constexpr int U = Unroll<NV>::value;
-  // Lanes past the row's last vector re-read the last valid vector (no branch in the load
-  // stream); their accumulators are never stored.
   int64_t off[NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    int idx = gl + G * v;
-    idx = idx < nvec ? idx : nvec - 1;
-    off[v] = (int64_t)idx * VEC;
-  }
+  lane_offsets<VEC, G, NV>(nvec, gl, off);
   for (int64_t base = beg; base < end; base += G) {
     int64_t rem = end - base;
     int n = rem < G ? (int)rem : G;
@@ -123,34 +175,7 @@ __device__ __forceinline__ void accumulate_range(int64_t beg, int64_t end, const
       cv = col[base + gl];
       if constexpr (HASVAL) wv = val[base + gl];
     }
-    int j = 0;
-    for (; j + U <= n; j += U) {
-      V xr[U][NV];
-      float w[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        int c = bcast_i<G>(cv, j + u);
-        w[u] = HASVAL ? bcast_f<G>(wv, j + u) : 1.0f;
-        const float* rp = x + (int64_t)c * ldx;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) xr[u][v] = *reinterpret_cast<const V*>(rp + off[v]);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) vupdate<VEC, OP, HASVAL>(acc[v], w[u], xr[u][v]);
-      }
-    }
-    for (; j < n; ++j) {
-      int c = bcast_i<G>(cv, j);
-      float w = HASVAL ? bcast_f<G>(wv, j) : 1.0f;
-      const float* rp = x + (int64_t)c * ldx;
-      V xr[NV];
-#pragma unroll
-      for (int v = 0; v < NV; ++v) xr[v] = *reinterpret_cast<const V*>(rp + off[v]);
-#pragma unroll
-      for (int v = 0; v < NV; ++v) vupdate<VEC, OP, HASVAL>(acc[v], w, xr[v]);
-    }
+    consume_batch<VEC, G, NV, OP, HASVAL>(cv, wv, n, x, ldx, off, acc);
   }
 }
 
@@ -228,39 +253,68 @@ __global__ __launch_bounds__(256) void k_spmm_rows_win(const int64_t* __restrict
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int gl = lane % G;
+  // A group handles up to MAXR consecutive rows (positions) per launch, software-pipelined: all their
+  // table entries are fetched first, then the first (col, val) batch and the y block of row i+1 are in
+  // flight while row i gathers -- the per-row chain table -> (col, y) -> gather overlaps across rows.
+  constexpr int MAXR = 4;
   const int64_t grp0 = (((int64_t)blockIdx.x * 4 + wave) * RPW + lane / G) * rpg;
-  for (int it = 0; it < rpg; ++it) {
-    const int64_t grp = grp0 + it;
-    if (grp >= count) return;
-    // three independent loads (the table holds absolute entry offsets): no perm -> rowptr -> col chain
-    int64_t row = (int64_t)perm[first + grp];
-    int64_t beg = wbeg[grp], end = wend[grp];
-    if constexpr (G == 64) {
-      row = uniform64(row);
-      beg = uniform64(beg);
-      end = uniform64(end);
+  if (grp0 >= count) return;
+  int64_t rem_rows = count - grp0;
+  const int nrow = rem_rows < rpg ? (int)rem_rows : rpg;
+  int64_t off[NV];
+  lane_offsets<VEC, G, NV>(nvec, gl, off);
+  const bool resume = !first_window || (flags & FLAG_ACCUM);
+  const bool finalize = last_window && (flags & FLAG_MEAN);
+  uint32_t mb[MAXR], me[MAXR], mrow[MAXR];
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    mb[i] = 0; me[i] = 0; mrow[i] = 0;
+    if (i < nrow) { mb[i] = wbeg[grp0 + i]; me[i] = wend[grp0 + i]; mrow[i] = perm[first + grp0 + i]; }
+  }
+  int cv_n = 0; float wv_n = 0.0f; V y_n[NV];
+  auto fetch = [&](uint32_t b, uint32_t e, uint32_t r, int& cv, float& wv, V (&yv)[NV]) {
+    const uint32_t len = e - b;
+    cv = 0; wv = 0.0f;
+    if ((uint32_t)gl < len) {
+      cv = col[(int64_t)b + gl];
+      if constexpr (HASVAL) wv = val[(int64_t)b + gl];
     }
-    // nothing to add and nothing to finalise: leave the row alone
-    if (end == beg && !first_window && !(last_window && (flags & FLAG_MEAN))) continue;
-    V acc[NV];
-    float* yr = y + row * ldy;
-    const bool resume = !first_window || (flags & FLAG_ACCUM);
+    const float* yr = y + (int64_t)r * ldy;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int idx = gl + G * v;
-      acc[v] = 0.0f;
-      if (resume && idx < nvec) acc[v] = *reinterpret_cast<const V*>(yr + (int64_t)idx * VEC);
+      yv[v] = 0.0f;
+      if (resume && idx < nvec) yv[v] = *reinterpret_cast<const V*>(yr + (int64_t)idx * VEC);
     }
-    accumulate_range<VEC, G, NV, OP_SUM, HASVAL>(beg, end, col, val, x, ldx, nvec, gl, acc);
-    float cnt = 0.0f;
-    if (last_window && (flags & FLAG_MEAN)) cnt = (float)(rowptr[row + 1] - rowptr[row]);
+  };
+  fetch(mb[0], me[0], mrow[0], cv_n, wv_n, y_n);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      int idx = gl + G * v;
-      if (idx < nvec) {
-        V a = acc[v];
-        if (cnt > 0.0f) a = vdiv<VEC>(a, cnt);
-        *reinterpret_cast<V*>(yr + (int64_t)idx * VEC) = a;
+  for (int i = 0; i < MAXR; ++i) {
+    if (i < nrow) {
+      int cv = cv_n; float wv = wv_n;
+      V acc[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] = y_n[v];
+      if (i + 1 < MAXR && i + 1 < nrow) fetch(mb[i + 1], me[i + 1], mrow[i + 1], cv_n, wv_n, y_n);
+      int64_t beg = mb[i], end = me[i], row = mrow[i];
+      if constexpr (G == 64) { beg = uniform64(beg); end = uniform64(end); row = uniform64(row); }
+      // nothing to add and nothing to finalise: leave the row alone
+      if (end != beg || first_window || finalize) {
+        const int n0 = end - beg < G ? (int)(end - beg) : G;
+        consume_batch<VEC, G, NV, OP_SUM, HASVAL>(cv, wv, n0, x, ldx, off, acc);
+        if (end - beg > G) accumulate_range<VEC, G, NV, OP_SUM, HASVAL>(beg + G, end, col, val, x, ldx, nvec, gl, acc);
+        float cnt = 0.0f;
+        if (finalize) cnt = (float)(rowptr[row + 1] - rowptr[row]);
+        float* yr = y + row * ldy;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          int idx = gl + G * v;
+          if (idx < nvec) {
+            V a = acc[v];
+            if (cnt > 0.0f) a = vdiv<VEC>(a, cnt);
+            *reinterpret_cast<V*>(yr + (int64_t)idx * VEC) = a;
+          }
+        }
       }
     }
   }
@@ -534,7 +588,8 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       const disco_schedule_info& s = *a.info;
       const uint32_t* wptr = reinterpret_cast<const uint32_t*>(s.sweep_ws);
       const int P = (int)s.sweep_windows;
-      const int rpg = tuning().win_rows_per_group > 0 ? tuning().win_rows_per_group : 1;
+      int rpg = tuning().win_rows_per_group > 0 ? tuning().win_rows_per_group : 2;
+      if (rpg > 4) rpg = 4;
       int64_t blocks = (count + 4 * RPW * rpg - 1) / (4 * RPW * rpg);
       if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
       for (int w = 0; w < P; ++w) {

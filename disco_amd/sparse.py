@@ -24,6 +24,9 @@ WIN_COLS = 128           # column block width of the windowed launches (libdisco
 WINDOW_BYTES = 6 << 20   # measured optimum on MI355X (4 MiB L2 per XCD): fewer, slightly over-sized windows win
 
 
+WIN_HUB_THRESHOLD, WIN_HUB_PIECE = 8192, 16384   # hub split used with windowed launches (tune_hub_windowed.log)
+
+
 def sweep_window_rows(feat: int, window_bytes: int = WINDOW_BYTES, cap: int = WIN_COLS) -> int:
     """Source rows per L2 window for feature width `feat`: the kernels cut wide features into balanced
     column blocks of at most `cap` floats (multiples of 32); one window of one block takes `window_bytes`."""
@@ -88,6 +91,7 @@ class SparseTensor:
         self._sizes = sparse_sizes
         self._sched = None          # (ws tensor, ScheduleInfo)
         self._sched_key = None
+        self._sched_auto = False
         self._sweep = None          # (window_rows, workspace tensor or None)
         self._t: Optional["SparseTensor"] = None
         self.storage = _Storage(self)
@@ -157,6 +161,7 @@ class SparseTensor:
     def set_value(self, value: Optional[torch.Tensor], layout: Optional[str] = None) -> "SparseTensor":
         out = SparseTensor(rowptr=self._rowptr, col=self._col32, value=value, sparse_sizes=self._sizes, is_sorted=True)
         out._sched, out._sched_key, out._sweep = self._sched, self._sched_key, self._sweep
+        out._sched_auto = getattr(self, "_sched_auto", False)
         return out
 
     def fill_value(self, fill: float, dtype=torch.float32) -> "SparseTensor":
@@ -206,8 +211,17 @@ class SparseTensor:
         With ``feat`` (the feature width about to be propagated) the L2-blocked sweep structure is
         attached as well when the graph re-uses source rows enough for it to pay
         (``sweep=None``: automatic; True / False force it)."""
-        key = (hub_threshold, hub_piece)
         lib = _lib.load()
+        if hub_threshold == 0 and hub_piece == 0:
+            if self._sched is not None and getattr(self, "_sched_auto", False):
+                hub_threshold, hub_piece = self._sched_key      # keep the automatic choice made first
+            elif feat is not None and sweep is not False and (sweep or self.sweep_pays(feat)):
+                # windowed launches visit a row once per window, so only much longer rows need splitting
+                hub_threshold, hub_piece = WIN_HUB_THRESHOLD, WIN_HUB_PIECE
+            auto = True
+        else:
+            auto = False
+        key = (hub_threshold, hub_piece)
         if self._sched is None or self._sched_key != key:
             assert self.device.type == "cuda", "schedules live on the GPU"
             n, nnz = self._sizes[0], self.nnz()
@@ -223,7 +237,7 @@ class SparseTensor:
                 keep = min(max(keep, 256), ws.numel())
                 if keep < ws.numel() // 2:
                     ws = ws[:keep].clone()
-            self._sched, self._sched_key = (ws, info), key
+            self._sched, self._sched_key, self._sched_auto = (ws, info), key, auto
             self._sweep = None
         ws, info = self._sched
         if feat is not None and sweep is not False:
