@@ -278,7 +278,7 @@ class SparseTensor:
         if n == 0 or m == 0 or self.nnz() >= 2 ** 32 - 1:
             return False
         windows = (m + sweep_window_rows(feat) - 1) // sweep_window_rows(feat)
-        return self.nnz() / n >= 8.0 * windows
+        return windows >= 2 and self.nnz() / n >= 8.0 * windows
 
     def __repr__(self) -> str:
         return f"SparseTensor(sizes={self._sizes}, nnz={self.nnz()}, has_value={self.has_value()}, device={self.device})"
