@@ -74,13 +74,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DISCO_DIST_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks share cards,
+    # halo rows staged through host memory); the driver's runs use RCCL, one rank per GPU.
+    backend = os.environ.get("DISCO_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from disco_amd import SparseTensor, _lib, graphgen, ops, utils
     lib = _lib.load()

@@ -39,6 +39,26 @@ def balanced_row_offsets(rowptr: torch.Tensor, world: int) -> List[int]:
     return offs
 
 
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None, async_op=False):
+    """``all_to_all_single``; device tensors under the gloo backend (rehearsals on a box without RCCL
+    peers, tests/test_gpu_dist.py) are staged through host memory, synchronously."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        o, i = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.all_to_all_single(o, i, out_splits, in_splits, group=group)
+        out.copy_(o)
+        return None
+    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
+
+
+def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None):
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+        return
+    dist.all_gather_into_tensor(out, inp, group=group)
+
+
 class RowPartition:
     """This rank's share of a row-partitioned square adjacency.
 
@@ -76,12 +96,12 @@ class RowPartition:
         send_counts = torch.zeros(world, dtype=torch.int64, device=dev)
         recv_counts = torch.tensor(self.recv_splits, dtype=torch.int64, device=dev)
         if world > 1:
-            dist.all_to_all_single(send_counts, recv_counts, group=group)
+            _all_to_all(send_counts, recv_counts, group=group)
         self.send_splits = [int(v) for v in send_counts.tolist()]
         want_local = need - bounds[torch.bucketize(need, bounds[1:], right=True)]  # ids local to their owner
         self.send_idx = torch.empty(sum(self.send_splits), dtype=torch.int64, device=dev)
         if world > 1:
-            dist.all_to_all_single(self.send_idx, want_local.contiguous(), self.send_splits, self.recv_splits, group=group)
+            _all_to_all(self.send_idx, want_local.contiguous(), self.send_splits, self.recv_splits, group=group)
         if self.send_idx.numel():
             assert int(self.send_idx.max()) < self.n_local and int(self.send_idx.min()) >= 0
         self._spmm = spmm_fn
@@ -115,8 +135,8 @@ class RowPartition:
         # whole padded rows travel (contiguous buffers): splits are in rows of `ld` floats
         sflat = self._send_buf[:max(ns, 0)].reshape(-1) if ns else self._send_buf[:0].reshape(-1)
         rflat = self._recv_buf[:self.n_halo].reshape(-1) if self.n_halo else self._recv_buf[:0].reshape(-1)
-        work = dist.all_to_all_single(rflat, sflat, [c * ld for c in self.recv_splits], [c * ld for c in self.send_splits],
-                                      group=self.group, async_op=True)
+        work = _all_to_all(rflat, sflat, [c * ld for c in self.recv_splits], [c * ld for c in self.send_splits],
+                           group=self.group, async_op=True)
         return work, recv
 
     def spmm(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
@@ -191,7 +211,7 @@ def build_weak_scaling_partition(spec, n_local: int, nnz_local: int, skew: float
     r_local[torch.isinf(r_local)] = 0
     if world > 1:
         r_all = torch.empty(n_global, dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(r_all, r_local.contiguous())
+        _all_gather_into(r_all, r_local.contiguous())
     else:
         r_all = r_local
     val = (r_local[row] * r_all[col]).to(torch.float32)
