@@ -58,7 +58,11 @@ _SIGNATURES = {
     "disco_sym_threshold_count": (c_int, [c_void_p, c_int64, c_int64, C.c_float, c_int, c_void_p, c_void_p]),
     "disco_sym_threshold_fill": (c_int, [c_void_p, c_int64, c_int64, C.c_float, c_int, c_void_p, c_int64, c_void_p, c_void_p,
                                          c_void_p]),
+    "disco_coo_to_csr_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "disco_coo_to_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                 C.POINTER(c_int64), c_void_p, c_size_t, c_void_p]),
 }
+COO_SYMMETRISE, COO_DUP_KEEP, COO_DUP_SUM, COO_DUP_FIRST = 1, 0, 2, 4
 
 # symbols that may legitimately be absent from an older build (none at the moment)
 _OPTIONAL = set()

@@ -35,6 +35,43 @@ def sweep_window_rows(feat: int, window_bytes: int = WINDOW_BYTES, cap: int = WI
     return max(64, window_bytes // (4 * blk))
 
 
+def coo_to_csr(row: torch.Tensor, col: torch.Tensor, value: Optional[torch.Tensor], sparse_sizes: Tuple[int, int],
+               dup: str = "keep", symmetrise: bool = False, want_value: Optional[bool] = None):
+    """(rowptr int64, col int32, value float32 | None) from raw COO edges with ``disco_coo_to_csr``
+    (device radix sort; replaces scipy ``csr_matrix`` / PyG ``to_undirected`` / the torch_sparse
+    constructor's ordering: /root/reference/utils.py:99-106, LargeScaleCondensing.py:486).
+    dup: "keep" (stable order), "sum" (float64 fold, csr_matrix), "first" (coalesce of unit weights)."""
+    assert row.is_cuda and col.is_cuda, "coo_to_csr runs on the GPU"
+    lib = _lib.load()
+    flags = {"keep": _lib.COO_DUP_KEEP, "sum": _lib.COO_DUP_SUM, "first": _lib.COO_DUP_FIRST}[dup]
+    if symmetrise:
+        flags |= _lib.COO_SYMMETRISE
+    row = row.to(torch.int64).contiguous()
+    col = col.to(torch.int64).contiguous()
+    if value is not None and value.dtype != torch.float32:
+        raise TypeError("coo_to_csr carries float32 values")
+    want_value = (value is not None) if want_value is None else want_value
+    e, (m, n) = int(row.numel()), sparse_sizes
+    cap = 2 * e if symmetrise else e
+    dev = row.device
+    with torch.cuda.device(dev):
+        nb = lib.disco_coo_to_csr_workspace_bytes(e, flags, int(want_value))
+        ws = torch.empty(max(int(nb), 256), dtype=torch.uint8, device=dev)
+        rowptr = torch.empty(m + 1, dtype=torch.int64, device=dev)
+        col_out = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        val_out = torch.empty(max(cap, 1), dtype=torch.float32, device=dev) if want_value else None
+        import ctypes
+        nnz = ctypes.c_int64(0)
+        _lib.check(lib.disco_coo_to_csr(_lib.ptr(row), _lib.ptr(col), _lib.ptr(value.contiguous()) if value is not None else None,
+                                        e, m, n, flags, _lib.ptr(rowptr), _lib.ptr(col_out), _lib.ptr(val_out),
+                                        ctypes.byref(nnz), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                   "disco_coo_to_csr")
+    k = int(nnz.value)
+    if k < cap // 2:       # do not pin a mostly empty allocation
+        return rowptr, col_out[:k].clone(), None if val_out is None else val_out[:k].clone()
+    return rowptr, col_out[:k], None if val_out is None else val_out[:k]
+
+
 class _Storage:
     """``adj.storage`` facade: ``row()``, ``col()``, ``rowptr()``, ``value()``."""
 
@@ -68,6 +105,10 @@ class SparseTensor:
             n = int(col.max()) + 1 if col.numel() else 0
             sparse_sizes = (m, n)
         sparse_sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
+        if rowptr is None and not is_sorted and col.is_cuda and row.numel() and (value is None or value.dtype == torch.float32):
+            # device build: stable radix sort, duplicates kept (torch_sparse.SparseTensor construction)
+            rowptr, col, value = coo_to_csr(row, col, value, sparse_sizes, dup="keep")
+            is_sorted = True
         if rowptr is None:
             row = row.to(torch.int64)
             col = col.to(torch.int64)

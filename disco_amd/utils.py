@@ -11,7 +11,7 @@ from typing import Optional, Tuple, Union
 import torch
 
 from . import _lib
-from .sparse import SparseTensor
+from .sparse import SparseTensor, coo_to_csr
 
 
 def is_sparse_tensor(tensor) -> bool:
@@ -150,11 +150,10 @@ def normalize_adj_csr(adj: SparseTensor) -> SparseTensor:
         # Structure of mx + I: a zero-valued diagonal entry is merged into every row (x + 0 is exact in
         # float32); the kernels add the 1 in float64, as scipy's `mx + sp.eye(n)` does.
         d = torch.arange(n, device=adj.device)
-        m = torch.sparse_coo_tensor(torch.stack([torch.cat([row, d]), torch.cat([col, d])]),
-                                    torch.cat([val.to(torch.float32), torch.zeros(n, dtype=torch.float32, device=adj.device)]),
-                                    adj.sparse_sizes()).coalesce()
-        adj = SparseTensor(row=m.indices()[0], col=m.indices()[1], value=m.values(),
-                           sparse_sizes=adj.sparse_sizes(), is_sorted=True)
+        rp, c32, v = coo_to_csr(torch.cat([row, d]), torch.cat([col, d]),
+                                torch.cat([val.to(torch.float32), torch.zeros(n, dtype=torch.float32, device=adj.device)]),
+                                adj.sparse_sizes(), dup="sum")
+        adj = SparseTensor(rowptr=rp, col=c32, value=v, sparse_sizes=adj.sparse_sizes(), is_sorted=True)
     lib = _lib.load()
     with torch.cuda.device(adj.device):
         s = _lib.current_stream(adj.device)
@@ -191,6 +190,30 @@ def normalize_adj_tensor(adj: torch.Tensor, sparse: bool = False):
     mx = r_mat_inv @ mx
     mx = mx @ r_mat_inv
     return mx
+
+
+def to_undirected(edge_index: torch.Tensor, edge_attr=None, num_nodes: Optional[int] = None) -> torch.Tensor:
+    """PyG ``to_undirected(edge_index, edge_attr=None, num_nodes=)`` as the reference calls it
+    (/root/reference/utils.py:100): both directions of every edge, duplicates removed, sorted by
+    (row, col).  One device radix sort (``disco_coo_to_csr`` with SYMMETRISE | DUP_FIRST)."""
+    if edge_attr is not None:
+        raise NotImplementedError("the reference only symmetrises unweighted edge lists (utils.py:100)")
+    _require_cuda(edge_index, "to_undirected")
+    n = maybe_num_nodes(edge_index, num_nodes)
+    rp, c32, _ = coo_to_csr(edge_index[0], edge_index[1], None, (n, n), dup="first", symmetrise=True, want_value=False)
+    row = torch.repeat_interleave(torch.arange(n, device=edge_index.device), rp[1:] - rp[:-1])
+    return torch.stack([row, c32.to(torch.int64)])
+
+
+def adjacency_from_edge_index(edge_index: torch.Tensor, num_nodes: int, undirected: bool = False) -> SparseTensor:
+    """``Pyg2Dpr``'s adjacency (/root/reference/utils.py:99-106): optional ``to_undirected``, then
+    ``csr_matrix((ones, (row, col)), shape=(n, n))`` -- duplicate edges are SUMMED (a doubled edge
+    weighs 2).  Built on the device; the result feeds ``normalize_adj_csr``."""
+    _require_cuda(edge_index, "adjacency_from_edge_index")
+    if undirected:
+        edge_index = to_undirected(edge_index, None, num_nodes)
+    rp, c32, v = coo_to_csr(edge_index[0], edge_index[1], None, (num_nodes, num_nodes), dup="sum", want_value=True)
+    return SparseTensor(rowptr=rp, col=c32, value=v, sparse_sizes=(num_nodes, num_nodes), is_sorted=True)
 
 
 def to_adj_t(adj) -> SparseTensor:

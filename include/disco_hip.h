@@ -201,6 +201,31 @@ int disco_sym_threshold_fill(const float* S, int64_t n, int64_t lds, float thres
 /* Benchmark / test knobs ("force_g", "force_nv", "max_vec", "sweep_mode", "win_cols", "sweep_blocks_per_cu"). */
 int disco_set_tuning(const char* key, int64_t value);
 
+/* ---- CSR construction from raw COO edges ---------------------------------------------
+ * Replaces the single-threaded host set-up of the reference: scipy `csr_matrix((ones,(row,col)))` with
+ * its duplicate summation (/root/reference/utils.py:104-106), PyG `to_undirected(edge_index)`
+ * (/root/reference/utils.py:99-100) and the row-major ordering of `SparseTensor(row=,col=,value=).t()`
+ * (/root/reference/LargeScaleCondensing.py:486).
+ *   flags = [DISCO_COO_SYMMETRISE] | one of DISCO_COO_DUP_{KEEP,SUM,FIRST}
+ *     SYMMETRISE : (col,row) is added for every (row,col) before sorting (square shapes only)
+ *     DUP_KEEP   : duplicates stay, in input order (stable sort)       -- torch_sparse.SparseTensor
+ *     DUP_SUM    : duplicates folded, values summed in float64 in input order, rounded once -- csr_matrix
+ *     DUP_FIRST  : duplicates folded, first value in input order kept  -- to_undirected / coalesce of unit weights
+ *   val may be NULL (unit weights); val_out may be NULL when only the structure is wanted (val must then
+ *   be NULL).  rowptr[n_rows+1], col_out / val_out need room for n_edges (2 n_edges with SYMMETRISE)
+ *   entries; *nnz_out (host) receives the number written.  Columns come out sorted inside every row.
+ *   Synchronises the stream once (the entry count is read back).  DISCO_EINVAL if an index lies
+ *   outside the shape. */
+#define DISCO_COO_SYMMETRISE 1
+#define DISCO_COO_DUP_KEEP 0
+#define DISCO_COO_DUP_SUM 2
+#define DISCO_COO_DUP_FIRST 4
+#define DISCO_COO_DUP_MASK 6
+size_t disco_coo_to_csr_workspace_bytes(int64_t n_edges, int flags, int with_values);
+int disco_coo_to_csr(const int64_t* row, const int64_t* col, const float* val, int64_t n_edges, int64_t n_rows,
+                     int64_t n_cols, int flags, int64_t* rowptr, int32_t* col_out, float* val_out, int64_t* nnz_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

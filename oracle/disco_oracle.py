@@ -156,6 +156,31 @@ def adj_t_from_coo(row, col, val, n):
     return coo_to_csr(col, row, val, n)
 
 
+def to_undirected(edge_index, num_nodes):
+    """PyG ``to_undirected(edge_index, edge_attr=None, num_nodes=)`` [torch_geometric 2.1.0, restated]:
+    concatenate both directions, ``coalesce`` = sort by row * N + col and drop repeats.  Call site:
+    /root/reference/utils.py:100."""
+    ei = np.asarray(edge_index, dtype=np.int64)
+    r = np.concatenate([ei[0], ei[1]])
+    c = np.concatenate([ei[1], ei[0]])
+    key = np.unique(r * num_nodes + c)
+    return np.stack([key // num_nodes, key % num_nodes])
+
+
+def pyg2dpr_adjacency(edge_index, num_nodes, undirected=False):
+    """``Pyg2Dpr.__init__`` (/root/reference/utils.py:99-106): optional to_undirected, then
+    ``sp.csr_matrix((np.ones(E), (row, col)), shape=(n, n))`` -- scipy itself, float64 ones,
+    duplicates summed; canonical (sorted) indices."""
+    import scipy.sparse as sp
+    ei = np.asarray(edge_index, dtype=np.int64)
+    if undirected:
+        ei = to_undirected(ei, num_nodes)
+    m = sp.csr_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(num_nodes, num_nodes))
+    m.sum_duplicates()
+    m.sort_indices()
+    return m.indptr.astype(np.int64), m.indices.astype(np.int64), m.data
+
+
 # --------------------------------------------------------------------------
 # A4/A5/A10: propagation
 # --------------------------------------------------------------------------

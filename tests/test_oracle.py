@@ -187,3 +187,14 @@ def test_edge_construction_variants():
     ti = torch.nonzero(a).T
     ei, ew = orc.edge_construction(S, thr, "transductive")
     assert np.array_equal(ei, ti.numpy()) and np.array_equal(ew, a[ti[0], ti[1]].numpy())
+
+
+def test_set_up_restatements_on_a_hand_checked_edge_list():
+    # edges 0->1 twice, 1->0, 2->2, 1->2: csr_matrix sums the doubled edge; to_undirected de-duplicates
+    ei = np.array([[0, 1, 0, 2, 1], [1, 0, 1, 2, 2]])
+    rp, col, data = orc.pyg2dpr_adjacency(ei, 3, undirected=False)
+    assert rp.tolist() == [0, 1, 3, 4] and col.tolist() == [1, 0, 2, 2] and data.tolist() == [2.0, 1.0, 1.0, 1.0]
+    und = orc.to_undirected(ei, 3)
+    assert und.tolist() == [[0, 1, 1, 2, 2], [1, 0, 2, 1, 2]]
+    rp, col, data = orc.pyg2dpr_adjacency(ei, 3, undirected=True)
+    assert rp.tolist() == [0, 1, 3, 5] and data.tolist() == [1.0] * 5
