@@ -155,3 +155,34 @@ def max_aggregate(adj: SparseTensor, x: torch.Tensor) -> torch.Tensor:
     if adj.has_value():
         adj = adj.set_value(None)
     return spmm_raw(adj, x, "max")
+
+
+def pair_gather(z: torch.Tensor, edge_index: torch.Tensor, sel: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None, err_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``concat((z[edge_index[0][sel]], z[edge_index[1][sel]]), dim=1)`` in one kernel
+    (/root/reference/LargeScaleCondensing.py:190-191), ``sel=None`` = every edge in order.
+    ``err_flag`` (int32 device scalar, optional) is set to 1 if an index is out of range; without it the
+    indices are checked here on the host side of the call (one device reduction)."""
+    if not (z.is_cuda and edge_index.is_cuda):
+        raise RuntimeError("disco_amd.pair_gather needs CUDA (HIP) tensors: there is no CPU fallback")
+    z = _as_operand(z)
+    ei = edge_index.to(torch.int64)
+    src, dst = ei[0].contiguous(), ei[1].contiguous()
+    n, w = z.shape
+    p = int(sel.numel()) if sel is not None else int(src.numel())
+    if sel is not None:
+        sel = sel.to(torch.int64).contiguous()
+    if out is None:
+        out = torch.empty((p, 2 * w), dtype=torch.float32, device=z.device)
+    assert out.shape == (p, 2 * w) and out.stride(1) == 1 and out.dtype == torch.float32
+    own_flag = err_flag is None
+    if own_flag:
+        err_flag = torch.zeros(1, dtype=torch.int32, device=z.device)
+    lib = _lib.load()
+    with torch.cuda.device(z.device):
+        _lib.check(lib.disco_pair_gather_f32(_lib.ptr(z), n, z.stride(0), w, _lib.ptr(sel), _lib.ptr(src), _lib.ptr(dst),
+                                             int(src.numel()), p, _lib.ptr(out), out.stride(0), _lib.ptr(err_flag),
+                                             _lib.current_stream(z.device)), "disco_pair_gather_f32")
+    if own_flag and int(err_flag.item()):
+        raise IndexError("pair_gather: edge selection or node index out of range")
+    return out

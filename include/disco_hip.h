@@ -226,6 +226,17 @@ int disco_coo_to_csr(const int64_t* row, const int64_t* col, const float* val, i
                      int64_t n_cols, int flags, int64_t* rowptr, int32_t* col_out, float* val_out, int64_t* nnz_out,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- Pair-embedding gather for the link predictor's training batches --------------------
+ * out[p, :] = [ Z[src[e], 0:width] | Z[dst[e], 0:width] ],  e = sel ? sel[p] : p,  p < n_pairs.
+ * Replaces `torch.concat((feat_transform[edge_index[0][index]], feat_transform[edge_index[1][index]]),
+ * dim=1).cpu() ... .cuda()` (/root/reference/LargeScaleCondensing.py:188-192) without the host round trip.
+ * Z is [n, ldz] float32, src/dst are int64[n_edges] (the two rows of an edge_index), sel is an optional
+ * int64[n_pairs] selection of edges, out is [n_pairs, ldo >= 2*width].  An index outside its range
+ * yields a zero row and sets *err_flag (optional device int, cleared by the caller) to 1. */
+int disco_pair_gather_f32(const float* Z, int64_t n, int64_t ldz, int64_t width, const int64_t* sel, const int64_t* src,
+                          const int64_t* dst, int64_t n_edges, int64_t n_pairs, float* out, int64_t ldo, int* err_flag,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif
