@@ -98,23 +98,27 @@ __global__ __launch_bounds__(256) void k_scorer_fold(const float* __restrict__ W
 // sum over the 32 lanes of a half (= 32 features) of w3 * relu(acc[g] + bias) for all 16 registers g at once:
 // butterfly transpose-reduce (8+4+2+1 exchanges), then one exchange with lane ^ 16.  Lane r returns the
 // total for register g = r & 15.
+template <int W>
+__device__ __forceinline__ void fold_step(float (&v)[16], int r) {
+  // lanes with bit W set keep the upper W values, the others the lower W; the partner supplies the matching half
+  const bool upper = (r & W) != 0;
+#pragma unroll
+  for (int q = 0; q < W; ++q) {
+    const float lo = v[q], hi = v[q + W];
+    const float keep = upper ? hi : lo;
+    const float send = upper ? lo : hi;
+    v[q] = keep + __shfl_xor(send, W);
+  }
+}
+
 __device__ __forceinline__ float reduce_features(const f32x16& acc, float bias, float w3v, int r) {
   float v[16];
 #pragma unroll
   for (int g = 0; g < 16; ++g) v[g] = w3v * fmaxf(acc[g] + bias, 0.0f);
-#pragma unroll
-  for (int step = 0; step < 4; ++step) {
-    const int width = 8 >> step;
-    const bool upper = (r & width) != 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if (q < width) {
-        const float keep = upper ? v[q + width] : v[q];
-        const float send = upper ? v[q] : v[q + width];
-        v[q] = keep + __shfl_xor(send, width);
-      }
-    }
-  }
+  fold_step<8>(v, r);
+  fold_step<4>(v, r);
+  fold_step<2>(v, r);
+  fold_step<1>(v, r);
   return v[0] + __shfl_xor(v[0], 16);
 }
 
@@ -127,9 +131,12 @@ __global__ __launch_bounds__(512) void k_scorer_pairs(const float* __restrict__ 
   constexpr int HH = H / 2;        // k values per lane half
   constexpr int LDA = H + 4;       // padded LDS row (floats): conflict-free ds_read_b128
   constexpr int NW = H / 32;       // waves with work
+  constexpr int PER = H / 8;       // h1 elements per thread and tile (= MFMA loop trip count HH / 4)
+  constexpr int PSTEP = 512 / H;   // pair rows between two elements of one thread
+  constexpr int DEPTH = PER < 8 ? PER : 8;   // V loads in flight per thread
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* a_lds = lds;                       // [64][LDA]
-  float* red = lds + 64 * LDA;              // [8][64] per-wave partial logits
+  // lds: h1 tile [2][64][LDA] (double buffered), then per-wave partial logits [2][8][64]
+  float* red_base = lds + 2 * 64 * LDA;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -151,34 +158,57 @@ __global__ __launch_bounds__(512) void k_scorer_pairs(const float* __restrict__ 
   const int64_t nj = j1 - j0;
   const int64_t jblocks = (nj + 63) / 64;
   const int64_t tiles = (i1 - i0) * jblocks;
-  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-    const int64_t i = i0 + t / jblocks;
-    const int64_t jb = j0 + (t % jblocks) * 64;
-    // ---- generate h1 tile: element e = tid + 512 q -> pair e / H, k = e % H -------------------------
-    {
-      constexpr int PER = 64 * H / 512;  // elements per thread
-      const int k = tid % H;
-      const float u = U[i * H + k];
+  // generation role of this thread: column k of pair rows pofs, pofs + PSTEP, ...
+  const int gk = tid % H, pofs = tid / H;
+  const int gen_off = pofs * LDA + gk;                 // + q * PSTEP * LDA
+  const int mma_off = r * LDA + hh * HH;               // + 32 * LDA for the second pair block
+
+  int64_t t = blockIdx.x;
+  if (t >= tiles) return;
+  {  // prologue: first tile straight into buffer 0
+    const int64_t i = i0 + t / jblocks, jb = j0 + (t % jblocks) * 64;
+    const int pmax = (int)((j1 - 1 - jb) < 63 ? (j1 - 1 - jb) : 63);
+    const float u = U[i * H + gk];
+    const float* vb = V + jb * H + gk;
 #pragma unroll 8
-      for (int q = 0; q < PER; ++q) {
-        const int p = (tid + 512 * q) / H;
-        int64_t j = jb + p;
-        j = j < j1 ? j : j1 - 1;
-        const float v = V[j * H + k];
-        a_lds[p * LDA + k] = fmaxf(u + v, 0.0f);
-      }
+    for (int q = 0; q < PER; ++q) {
+      int p = q * PSTEP + pofs;
+      const int pc = p < pmax ? p : pmax;
+      lds[gen_off + q * PSTEP * LDA] = fmaxf(u + vb[pc * H], 0.0f);
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; t < tiles; t += gridDim.x) {
+    const int64_t i = i0 + t / jblocks, jb = j0 + (t % jblocks) * 64;
+    // the tile generated while this one is multiplied (the last round regenerates its own tile: harmless)
+    const int64_t tn = t + gridDim.x < tiles ? t + gridDim.x : t;
+    const int64_t in = i0 + tn / jblocks, jbn = j0 + (tn % jblocks) * 64;
+    const int pmax = (int)((j1 - 1 - jbn) < 63 ? (j1 - 1 - jbn) : 63);
+    const float un = U[in * H + gk];
+    const float* vb = V + jbn * H + gk;
+    const float* a_cur = lds + buf * (64 * LDA);
+    float* a_nxt = lds + (buf ^ 1) * (64 * LDA) + gen_off;
+    float ring[DEPTH];
+    f32x16 acc0 = {0}, acc1 = {0};
+    const float* a0 = a_cur + mma_off;
+    const float* a1 = a0 + 32 * LDA;
+    f4s x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
     if (active) {
-      f32x16 acc0 = {0}, acc1 = {0};
-      const float* a0 = a_lds + r * LDA + hh * HH;
-      const float* a1 = a0 + 32 * LDA;
-      f4s x0 = *reinterpret_cast<const f4s*>(a0);
-      f4s x1 = *reinterpret_cast<const f4s*>(a1);
+      x0 = *reinterpret_cast<const f4s*>(a0);
+      x1 = *reinterpret_cast<const f4s*>(a1);
+    }
 #pragma unroll
-      for (int m = 0; m < HH; m += 4) {
+    for (int it = 0; it < PER; ++it) {
+      {  // issue the V load of element `it` of the next tile
+        const int p = it * PSTEP + pofs;
+        const int pc = p < pmax ? p : pmax;
+        ring[it % DEPTH] = vb[pc * H];
+      }
+      if (active) {
         // fragments of the next step are fetched while this step's 8 MFMAs issue; the scheduling barrier keeps
-        // the compiler from hoisting more LDS reads than that (register budget: 128 for W2', 32 accumulators)
+        // the compiler from hoisting more LDS reads / V loads than that (register budget: 128 for W2')
+        const int m = 4 * it;
         f4s n0 = x0, n1 = x1;
         if (m + 4 < HH) {
           n0 = *reinterpret_cast<const f4s*>(a0 + m + 4);
@@ -190,8 +220,17 @@ __global__ __launch_bounds__(512) void k_scorer_pairs(const float* __restrict__ 
           acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[q], breg[m + q], acc1, 0, 0, 0);
         }
         x0 = n0; x1 = n1;
-        __builtin_amdgcn_sched_barrier(0);
       }
+      if (it >= DEPTH - 1) {  // retire the oldest load into the other buffer
+        const int e = it - (DEPTH - 1);
+        a_nxt[e * PSTEP * LDA] = fmaxf(un + ring[e % DEPTH], 0.0f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int e = PER - (DEPTH - 1); e < PER; ++e) a_nxt[e * PSTEP * LDA] = fmaxf(un + ring[e % DEPTH], 0.0f);
+    float* red = red_base + buf * (8 * 64);
+    if (active) {
       // epilogue: h2 = relu(acc + b2'), partial logit = sum over this wave's 32 features of w3 * h2.
       // acc register g of lane (r, hh) is pair row (g & 3) + 8 (g >> 2) + 4 hh, feature r.
       const float s0 = reduce_features(acc0, bias, w3v, r);
@@ -201,6 +240,8 @@ __global__ __launch_bounds__(512) void k_scorer_pairs(const float* __restrict__ 
       if (r < 16) red[wave * 64 + prow] = s0;
       else red[wave * 64 + 32 + prow] = s1;
     }
+    // one barrier per tile: the next h1 tile and this tile's partial logits are complete, and nobody still
+    // reads the buffer the next round overwrites (red is double buffered for the same reason)
     __syncthreads();
     if (tid < 64) {
       float s = b3v;
@@ -212,8 +253,7 @@ __global__ __launch_bounds__(512) void k_scorer_pairs(const float* __restrict__ 
         out[(i - i0) * ldo + (j - j0)] = s;
       }
     }
-    // the next tile's generation may not overwrite a_lds / red before everybody is done reading
-    __syncthreads();
+    buf ^= 1;
   }
 }
 
@@ -310,7 +350,7 @@ static int launch_pairs(const char* w, const ScorerWs& L, int64_t i0, int64_t i1
   const int64_t tiles = (i1 - i0) * ((j1 - j0 + 63) / 64);
   int64_t blocks = tiles < 256 * 4 ? tiles : 256 * 4;
   if (blocks < 1) return DISCO_OK;
-  const size_t lds_bytes = (size_t)(64 * (H + 4) + 8 * 64) * sizeof(float);
+  const size_t lds_bytes = (size_t)(2 * 64 * (H + 4) + 2 * 8 * 64) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scorer_pairs<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes);
   if (e != hipSuccess) { set_last_hip_error((int)e); return DISCO_EHIP; }
