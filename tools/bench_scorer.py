@@ -52,7 +52,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.ref_rows):
         row = m.inference(torch.cat([Z[[i] * args.n], Z[np.arange(args.n)]], axis=1)).detach().cpu()
-    t_ref = (time.perf_counter() - t0) / args.ref_rows * args.n
+    t_ref = (time.perf_counter() - t0) / max(args.ref_rows, 1) * args.n
     print(json.dumps({"n": args.n, "d": args.d, "pairs_per_s": pairs / t, "score_s": t, "tflops_layer2": flops / t / 1e12,
                       "frac_fp32_mfma_peak": flops / t / 157.3e12, "edge_construction_total_s": t_edges, "edges_kept": int(ew.numel()),
                       "reference_style_torch_loop_s_extrapolated": t_ref, "speedup_vs_loop": t_ref / t_edges}))
