@@ -143,6 +143,7 @@ extern "C" int disco_set_tuning(const char* key, int64_t value) {
   else if (!strcmp(key, "win_cols")) t.win_cols = (int)value;
   else if (!strcmp(key, "win_rpg")) t.win_rows_per_group = (int)value;
   else if (!strcmp(key, "sweep_blocks_per_cu")) t.sweep_blocks_per_cu = (int)value;
+  else if (!strcmp(key, "addr24")) t.addr24 = (int)value;
   else return DISCO_EINVAL;
   return DISCO_OK;
 }

@@ -109,7 +109,22 @@ __device__ __forceinline__ void lane_offsets(int nvec, int gl, int64_t (&off)[NV
 }
 
 // Consume one cooperative batch: lane j of the group holds entry j (column cv, value wv), n <= G valid.
-template <int VEC, int G, int NV, int OP, bool HASVAL>
+// Row gather address.  A24 (host-checked: columns < 2^24, row pitch < 2^24 bytes, table < 4 GiB): the byte
+// offset col * pitch + lane offset is ONE full-rate v_mad_u32_u24 and the load takes the uniform base from
+// SGPRs; otherwise a full 64-bit multiply-add per gather (three quarter-rate multiplies on gfx950, which
+// made the L2-blocked kernel VALU-bound: profiles/r1/pmc_sq_instmix.csv).
+template <int VEC, bool A24>
+__device__ __forceinline__ typename Vec<VEC>::type gather_vec(const float* __restrict__ x, int64_t ldx, int c, int64_t off) {
+  typedef typename Vec<VEC>::type V;
+  if constexpr (A24) {
+    const uint32_t bo = __umul24((uint32_t)c, (uint32_t)ldx * 4u) + (uint32_t)off * 4u;
+    return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(x) + bo);
+  } else {
+    return *reinterpret_cast<const V*>(x + (int64_t)c * ldx + off);
+  }
+}
+
+template <int VEC, int G, int NV, int OP, bool HASVAL, bool A24>
 __device__ __forceinline__ void consume_batch(int cv, float wv, int n, const float* __restrict__ x, int64_t ldx,
                                               const int64_t (&off)[NV], typename Vec<VEC>::type (&acc)[NV]) {
   typedef typename Vec<VEC>::type V;
@@ -122,9 +137,8 @@ __device__ __forceinline__ void consume_batch(int cv, float wv, int n, const flo
     for (int u = 0; u < U; ++u) {
       int c = bcast_i<G>(cv, j + u);
       w[u] = HASVAL ? bcast_f<G>(wv, j + u) : 1.0f;
-      const float* rp = x + (int64_t)c * ldx;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) xr[u][v] = *reinterpret_cast<const V*>(rp + off[v]);
+      for (int v = 0; v < NV; ++v) xr[u][v] = gather_vec<VEC, A24>(x, ldx, c, off[v]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -143,9 +157,8 @@ __device__ __forceinline__ void consume_batch(int cv, float wv, int n, const flo
       const int ju = j + u < n ? j + u : n - 1;
       int c = bcast_i<G>(cv, ju);
       w[u] = HASVAL ? bcast_f<G>(wv, ju) : 1.0f;
-      const float* rp = x + (int64_t)c * ldx;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) xr[u][v] = *reinterpret_cast<const V*>(rp + off[v]);
+      for (int v = 0; v < NV; ++v) xr[u][v] = gather_vec<VEC, A24>(x, ldx, c, off[v]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -159,7 +172,7 @@ __device__ __forceinline__ void consume_batch(int cv, float wv, int n, const flo
 
 // Accumulate entries [beg, end) of one CSR row into acc[NV].  All lanes of the group call this
 // with the same (beg, end); lane `gl` owns vectors gl + G*v.
-template <int VEC, int G, int NV, int OP, bool HASVAL>
+template <int VEC, int G, int NV, int OP, bool HASVAL, bool A24 = false>
 __device__ __forceinline__ void accumulate_range(int64_t beg, int64_t end, const int32_t* __restrict__ col,
                                                  const float* __restrict__ val, const float* __restrict__ x,
                                                  int64_t ldx, int nvec, int gl,
@@ -175,7 +188,7 @@ __device__ __forceinline__ void accumulate_range(int64_t beg, int64_t end, const
       cv = col[base + gl];
       if constexpr (HASVAL) wv = val[base + gl];
     }
-    consume_batch<VEC, G, NV, OP, HASVAL>(cv, wv, n, x, ldx, off, acc);
+    consume_batch<VEC, G, NV, OP, HASVAL, A24>(cv, wv, n, x, ldx, off, acc);
   }
 }
 
@@ -189,7 +202,7 @@ template <int VEC> __device__ __forceinline__ typename Vec<VEC>::type vdiv(typen
 }
 
 // ---- rows below the hub threshold: one group of G lanes per row ---------------------------------
-template <int VEC, int G, int NV, int OP, bool HASVAL>
+template <int VEC, int G, int NV, int OP, bool HASVAL, bool A24>
 __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                    const float* __restrict__ val, const float* __restrict__ x,
                                                    int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ r
   V acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) vinit<VEC, OP>(acc[v]);
-  accumulate_range<VEC, G, NV, OP, HASVAL>(beg, end, col, val, x, ldx, nvec, gl, acc);
+  accumulate_range<VEC, G, NV, OP, HASVAL, A24>(beg, end, col, val, x, ldx, nvec, gl, acc);
   const bool empty = end == beg;
   const float cnt = (float)(end - beg);
   const bool mean = flags & FLAG_MEAN, accum = flags & FLAG_ACCUM;
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ r
 // block per window.  Windows are visited in ascending column order, i.e. each row still sums its entries
 // in CSR order: the only difference to k_spmm_rows is that the running sum passes through memory (no
 // rounding: float32 in, float32 out) -- same bits.
-template <int VEC, int G, int NV, bool HASVAL>
+template <int VEC, int G, int NV, bool HASVAL, bool A24>
 __global__ __launch_bounds__(256) void k_spmm_rows_win(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                        const float* __restrict__ val, const float* __restrict__ x,
                                                        int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
@@ -301,8 +314,8 @@ __global__ __launch_bounds__(256) void k_spmm_rows_win(const int64_t* __restrict
       // nothing to add and nothing to finalise: leave the row alone
       if (end != beg || first_window || finalize) {
         const int n0 = end - beg < G ? (int)(end - beg) : G;
-        consume_batch<VEC, G, NV, OP_SUM, HASVAL>(cv, wv, n0, x, ldx, off, acc);
-        if (end - beg > G) accumulate_range<VEC, G, NV, OP_SUM, HASVAL>(beg + G, end, col, val, x, ldx, nvec, gl, acc);
+        consume_batch<VEC, G, NV, OP_SUM, HASVAL, A24>(cv, wv, n0, x, ldx, off, acc);
+        if (end - beg > G) accumulate_range<VEC, G, NV, OP_SUM, HASVAL, A24>(beg + G, end, col, val, x, ldx, nvec, gl, acc);
         float cnt = 0.0f;
         if (finalize) cnt = (float)(rowptr[row + 1] - rowptr[row]);
         float* yr = y + row * ldy;
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(256) void k_spmm_rows_win(const int64_t* __restrict
 }
 
 // ---- hub rows: one 512-thread workgroup per piece, partial sums staged in LDS ----------------------
-template <int VEC, int G, int NV, int OP, bool HASVAL>
+template <int VEC, int G, int NV, int OP, bool HASVAL, bool A24>
 __global__ __launch_bounds__(512) void k_spmm_hub(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                   const float* __restrict__ val, const float* __restrict__ x,
                                                   int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
@@ -350,7 +363,7 @@ __global__ __launch_bounds__(512) void k_spmm_hub(const int64_t* __restrict__ ro
   V acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) vinit<VEC, OP>(acc[v]);
-  accumulate_range<VEC, G, NV, OP, HASVAL>(b, e, col, val, x, ldx, nvec, gl, acc);
+  accumulate_range<VEC, G, NV, OP, HASVAL, A24>(b, e, col, val, x, ldx, nvec, gl, acc);
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     int idx = gl + G * v;
@@ -550,11 +563,12 @@ struct SpmmArgs {
   const int64_t* rowptr; const int32_t* col; const float* val; int64_t n_rows;
   const float* x; int64_t ldx; float* y; int64_t ldy; int64_t F; int reduce;
   const char* sched; const disco_schedule_info* info; float* partial; int64_t ldp; hipStream_t stream;
+  bool addr24 = false;   // gather addresses fit v_mad_u32_u24 (set by spmm_dispatch)
 };
 
 static int device_cus();
 
-template <int VEC, int G, int NV, int OP, bool HASVAL>
+template <int VEC, int G, int NV, int OP, bool HASVAL, bool A24>
 static int launch_cfg(const SpmmArgs& a, int nvec) {
   const int mean = (a.reduce == DISCO_REDUCE_MEAN ? FLAG_MEAN : 0) | (a.reduce == DISCO_REDUCE_SUM_ACC ? FLAG_ACCUM : 0);
   constexpr int RPW = 64 / G;
@@ -567,7 +581,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
     count = s.n_rows - s.n_hub_rows;
     if (s.n_hub_pieces > 0) {
       size_t lds_bytes = (size_t)(512 / G) * nvec * VEC * sizeof(float);
-      hipLaunchKernelGGL((k_spmm_hub<VEC, G, NV, OP, HASVAL>), dim3((unsigned)s.n_hub_pieces), dim3(512), lds_bytes, a.stream,
+      hipLaunchKernelGGL((k_spmm_hub<VEC, G, NV, OP, HASVAL, A24>), dim3((unsigned)s.n_hub_pieces), dim3(512), lds_bytes, a.stream,
                          a.rowptr, a.col, a.val, a.x, a.ldx, a.y, a.ldy, nvec,
                          reinterpret_cast<const int32_t*>(a.sched + s.off_piece_row),
                          reinterpret_cast<const int64_t*>(a.sched + s.off_piece_begin),
@@ -593,7 +607,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       int64_t blocks = (count + 4 * RPW * rpg - 1) / (4 * RPW * rpg);
       if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
       for (int w = 0; w < P; ++w) {
-        hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, HASVAL>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
+        hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, HASVAL, A24>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
                            a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, wptr + (int64_t)w * s.sweep_count_padded,
                            wptr + (int64_t)(w + 1) * s.sweep_count_padded, w == 0, w == P - 1, mean, rpg);
       }
@@ -616,7 +630,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
   if (count > 0 && !swept) {
     int64_t blocks = (count + 4 * RPW - 1) / (4 * RPW);
     if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
-    hipLaunchKernelGGL((k_spmm_rows<VEC, G, NV, OP, HASVAL>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
+    hipLaunchKernelGGL((k_spmm_rows<VEC, G, NV, OP, HASVAL, A24>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
                        a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, mean);
   }
   hipError_t e = hipGetLastError();
@@ -624,12 +638,21 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
   return DISCO_OK;
 }
 
-template <int VEC, int G, int NV>
-static int launch_op(const SpmmArgs& a, int nvec) {
+template <int VEC, int G, int NV, bool A24>
+static int launch_op2(const SpmmArgs& a, int nvec) {
   const bool hv = a.val != nullptr;
   if (a.reduce == DISCO_REDUCE_MAX)
-    return hv ? launch_cfg<VEC, G, NV, OP_MAX, true>(a, nvec) : launch_cfg<VEC, G, NV, OP_MAX, false>(a, nvec);
-  return hv ? launch_cfg<VEC, G, NV, OP_SUM, true>(a, nvec) : launch_cfg<VEC, G, NV, OP_SUM, false>(a, nvec);
+    return hv ? launch_cfg<VEC, G, NV, OP_MAX, true, A24>(a, nvec) : launch_cfg<VEC, G, NV, OP_MAX, false, A24>(a, nvec);
+  return hv ? launch_cfg<VEC, G, NV, OP_SUM, true, A24>(a, nvec) : launch_cfg<VEC, G, NV, OP_SUM, false, A24>(a, nvec);
+}
+
+template <int VEC, int G, int NV>
+static int launch_op(const SpmmArgs& a, int nvec) {
+  // 24-bit address arithmetic (gather_vec) for the 128-bit path when the operand allows it
+  if constexpr (VEC == 4) {
+    if (a.addr24) return launch_op2<VEC, G, NV, true>(a, nvec);
+  }
+  return launch_op2<VEC, G, NV, false>(a, nvec);
 }
 
 template <int VEC>
@@ -684,6 +707,8 @@ int spmm_dispatch(const SpmmArgs& a0) {
   // Columns are processed in blocks of at most 5*64 vectors (one pass for F <= 1280 at VEC=4).
   int vec = pick_vec(a.x, a.ldx, a.y, a.ldy, a.partial, a.ldp, a.F);
   int64_t max_cols = (int64_t)5 * 64 * vec;
+  a.addr24 = tuning().addr24 && a.info && a.info->n_cols > 0 && a.info->n_cols <= (1 << 24) && a.ldx * 4 < (1 << 24) &&
+             a.info->n_cols * a.ldx * 4 <= 0xffffffffLL;
   if (vec >= 2 && a.reduce != DISCO_REDUCE_MAX && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && tuning().sweep_mode) {
     // L2-blocked modes work on balanced column blocks (multiples of 32 floats): <= 256 floats for the
     // persistent sweep kernel (one float4 per lane), `win_cols` (default 128) for the windowed launches

@@ -278,6 +278,7 @@ class SparseTensor:
                 keep = min(max(keep, 256), ws.numel())
                 if keep < ws.numel() // 2:
                     ws = ws[:keep].clone()
+            info.n_cols = self._sizes[1]      # every col[] entry is < sizes[1] (checked at construction)
             self._sched, self._sched_key, self._sched_auto = (ws, info), key, auto
             self._sweep = None
         ws, info = self._sched

@@ -61,6 +61,11 @@ typedef struct disco_schedule_info {
   /* optional L2-blocked sweep structure, filled by disco_sweep_build (0 / NULL when absent) */
   int64_t sweep_windows, sweep_window_rows, sweep_count_padded, sweep_n_cols;
   const void* sweep_ws;    /* DEVICE pointer kept inside this host struct */
+  /* Optional hint set by the CALLER after disco_schedule_build (which zeroes it): number of rows of x,
+   * i.e. every col[] entry is < n_cols.  When n_cols <= 2^24, the row pitch of x is < 2^24 bytes and
+   * n_cols * pitch < 4 GiB, the gathers use 24-bit multiply / 32-bit offset addressing (one VALU op per
+   * gather instead of a 64-bit multiply).  0 = unknown: 64-bit addressing. */
+  int64_t n_cols;
 } disco_schedule_info;
 
 int disco_abi_version(void);

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--mode", default="2", help="comma list: 1 = persistent sweep kernel, 2 = windowed launches")
     ap.add_argument("--rpg", default="4", help="comma list: rows per lane group per windowed launch")
     ap.add_argument("--wincols", default="128", help="comma list: column block width of the windowed launches")
+    ap.add_argument("--addr24", default="1", help="comma list of 0/1: 24-bit gather addressing")
     ap.add_argument("--ncols", type=int, default=0, help="gather from a table of this many rows (rectangular, unnormalised)")
     args = ap.parse_args()
 
@@ -78,8 +79,9 @@ def main():
                                             for mode in ([int(v) for v in args.mode.split(",")] if sw else [0]):
                                                 for wc in ([int(v) for v in args.wincols.split(",")] if sw and mode == 2 else [0]):
                                                     for rpg in ([int(v) for v in args.rpg.split(",")] if sw and mode == 2 else [0]):
-                                                        variants.append(dict(ld=ld, lib=libname, order=order, hub=hub, force=force, maxvec=mv,
-                                                                             slices=s, sweep=sw, wkb=wkb, bpc=bpc, mode=mode, wc=wc, rpg=rpg))
+                                                        for a24 in [int(v) for v in args.addr24.split(",")]:
+                                                            variants.append(dict(ld=ld, lib=libname, order=order, hub=hub, force=force, maxvec=mv,
+                                                                                 slices=s, sweep=sw, wkb=wkb, bpc=bpc, mode=mode, wc=wc, rpg=rpg, a24=a24))
 
     bufs = {}
     scheds = {}
@@ -103,6 +105,7 @@ def main():
                 t = thr if thr else 2048
                 _lib.check(lib.disco_schedule_build(adj._rowptr.data_ptr(), n, nnz, -t if v["order"] == "natural" else thr, piece,
                                                     ws.data_ptr(), ws.numel(), info, stream), "schedule")
+                info.n_cols = adj.size(1)
                 sb = lib.disco_spmm_workspace_bytes(info, F)
                 sws = torch.empty(max(int(sb), 16), dtype=torch.uint8, device=dev)
                 swp = None
@@ -122,6 +125,7 @@ def main():
             lib.disco_set_tuning(b"sweep_mode", v["mode"])
             lib.disco_set_tuning(b"win_cols", v["wc"])
             lib.disco_set_tuning(b"win_rpg", v["rpg"])
+            lib.disco_set_tuning(b"addr24", v["a24"])
             if v["force"] == "auto":
                 lib.disco_set_tuning(b"force_g", 0)
                 lib.disco_set_tuning(b"force_nv", 0)
