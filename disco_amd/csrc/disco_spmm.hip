@@ -157,8 +157,12 @@ __device__ __forceinline__ void consume_batch(int cv, float wv, int n, const flo
       const int ju = j + u < n ? j + u : n - 1;
       int c = bcast_i<G>(cv, ju);
       w[u] = HASVAL ? bcast_f<G>(wv, ju) : 1.0f;
+      // slots past the end are switched off by the execution mask: they cost no cache bandwidth
 #pragma unroll
-      for (int v = 0; v < NV; ++v) xr[u][v] = gather_vec<VEC, A24>(x, ldx, c, off[v]);
+      for (int v = 0; v < NV; ++v) {
+        xr[u][v] = 0.0f;
+        if (j + u < n) xr[u][v] = gather_vec<VEC, A24>(x, ldx, c, off[v]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
