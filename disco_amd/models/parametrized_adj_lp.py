@@ -111,8 +111,15 @@ class PGE_Edge(nn.Module):
     def edge_construction(self, Z: torch.Tensor, threshold: float, variant: str = "transductive"):
         """(edge_index int64 [2, E], edge_weight float32 [E]) of the condensed graph, on the GPU:
         scores -> (S + S^T)/2 -> threshold / unit diagonal in the order of `variant` -> nonzero."""
+        return self.edges_from_scores(self.score_all_pairs(Z), threshold, variant)
+
+    @staticmethod
+    @torch.no_grad()
+    def edges_from_scores(S: torch.Tensor, threshold: float, variant: str = "transductive"):
+        """Symmetrise / threshold / unit diagonal / ``nonzero`` of a full score matrix (the tail of the three
+        ``edge_construction`` variants), ``disco_sym_threshold_count/fill``."""
         v = _VARIANTS[variant]
-        S = self.score_all_pairs(Z)
+        Z = S
         n = S.shape[0]
         lib = _lib.load()
         dev = Z.device

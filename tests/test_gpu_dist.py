@@ -58,3 +58,36 @@ def test_two_ranks_one_gpu_matches_global_oracle(F, tmp_path):
     assert np.all(np.abs(got - ref) <= RTOL * K * bound + 1e-30)
     halo = np.array([np.load(tmp_path / f"halo{r}.npy") for r in range(world)])
     assert halo[:, 0].sum() == halo[:, 1].sum() > 0
+
+
+def _scorer_worker(rank, world, port, n, d, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disco_amd.dist import sharded_edge_construction
+        from disco_amd.models.parametrized_adj_lp import PGE_Edge
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(3)
+        pge = PGE_Edge(nfeat=d, nhid=64, device=dev).to(dev).eval()
+        Z = torch.randn(n, d, device=dev)
+        for variant in ("transductive", "inductive", "sampled"):
+            ei, ew = sharded_edge_construction(pge, Z, 0.5, variant)
+            torch.save((ei.cpu(), ew.cpu()), os.path.join(result_dir, f"{variant}{rank}.pt"))
+        if rank == 0:
+            for variant in ("transductive", "inductive", "sampled"):
+                ei, ew = pge.edge_construction(Z, 0.5, variant)
+                torch.save((ei.cpu(), ew.cpu()), os.path.join(result_dir, f"{variant}_single.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_edge_construction_equals_single_gpu(tmp_path):
+    n, d, world = 333, 12, 2          # 333 rows do not divide evenly: the last block is padded
+    mp.spawn(_scorer_worker, args=(world, _free_port(), n, d, str(tmp_path)), nprocs=world, join=True)
+    for variant in ("transductive", "inductive", "sampled"):
+        ref_ei, ref_ew = torch.load(tmp_path / f"{variant}_single.pt", weights_only=True)
+        assert ref_ei.shape[1] > n
+        for r in range(world):
+            ei, ew = torch.load(tmp_path / f"{variant}{r}.pt", weights_only=True)
+            assert torch.equal(ei, ref_ei) and torch.equal(ew, ref_ew), (variant, r)
