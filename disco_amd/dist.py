@@ -249,3 +249,61 @@ def sharded_edge_construction(pge_edge, Z: torch.Tensor, threshold: float, varia
     S = torch.empty((world * per, n), dtype=torch.float32, device=Z.device)
     _all_gather_into(S, block, group)
     return pge_edge.edges_from_scores(S[:n], threshold, variant)
+
+
+def normalize_adj_partition(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], col_offsets: List[int],
+                            rank: int, world: int, group=None):
+    """``normalize_adj`` (/root/reference/utils.py:406-435, the A3 semantics of ``utils.normalize_adj_csr``)
+    on a row partition (gcn_norm row): the row sums are local, the ``mx[0,0] == 0`` self-loop
+    rule is decided by the owner of row 0 and broadcast, and the only exchange is ONE all-gather of the
+    N-vector of row sums (``r[col]`` is needed for remote columns).  Input: CSR of this rank's rows with
+    GLOBAL column ids (duplicates already summed).  Returns (rowptr, col int64, val float32) of the
+    normalised block -- feed it to ``RowPartition``.  Same kernels, same bits as the single-GPU path."""
+    from . import _lib
+    from .sparse import coo_to_csr
+    dev = col.device
+    assert dev.type == "cuda", "normalize_adj_partition runs on the GPU"
+    lo, hi = col_offsets[rank], col_offsets[rank + 1]
+    n_local, n_global = hi - lo, col_offsets[-1]
+    assert rowptr.numel() == n_local + 1
+    col = col.to(torch.int64)
+    val = torch.ones(col.numel(), dtype=torch.float32, device=dev) if val is None else val.to(torch.float32)
+    row = torch.repeat_interleave(torch.arange(n_local, device=dev), rowptr[1:] - rowptr[:-1])
+    flag = torch.zeros(1, dtype=torch.int64)
+    if lo == 0 and n_local > 0:
+        flag[0] = int(bool(((row == 0) & (col == 0) & (val != 0)).any()))
+    if world > 1:
+        owner = next(g for g in range(world) if col_offsets[g + 1] > 0)
+        dist.broadcast(flag, src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
+    add_identity = 0 if int(flag[0]) else 1
+    if add_identity:
+        d = torch.arange(n_local, device=dev)
+        rowptr, c32, val = coo_to_csr(torch.cat([row, d]), torch.cat([col, d + lo]),
+                                      torch.cat([val, torch.zeros(n_local, dtype=torch.float32, device=dev)]),
+                                      (n_local, n_global), dup="sum")
+    else:
+        c32 = col.to(torch.int32)
+    lib = _lib.load()
+    per = max(col_offsets[g + 1] - col_offsets[g] for g in range(world))
+    with torch.cuda.device(dev):
+        s = _lib.current_stream(dev)
+        rs = torch.zeros(per, dtype=torch.float64, device=dev)
+        _lib.check(lib.disco_csr_rowsum_f64(_lib.ptr(rowptr), _lib.ptr(val), n_local, add_identity, _lib.ptr(rs), s),
+                   "disco_csr_rowsum_f64")
+        if world > 1:
+            padded = torch.empty(world * per, dtype=torch.float64, device=dev)
+            _all_gather_into(padded, rs, group)
+            r_all = torch.cat([padded[g * per: g * per + col_offsets[g + 1] - col_offsets[g]] for g in range(world)])
+        else:
+            r_all = rs[:n_local].clone()
+        # the scaling kernel indexes r[] by global row and column: run it on the global row range with every
+        # row outside this rank's block empty
+        nnz = int(c32.numel())
+        rp_g = torch.empty(n_global + 1, dtype=torch.int64, device=dev)
+        rp_g[:lo] = 0
+        rp_g[lo:hi + 1] = rowptr
+        rp_g[hi + 1:] = nnz
+        out = torch.empty(nnz, dtype=torch.float32, device=dev)
+        _lib.check(lib.disco_gcn_norm_csr_f32(_lib.ptr(rp_g), _lib.ptr(c32), _lib.ptr(val), n_global, add_identity,
+                                              _lib.ptr(r_all), _lib.ptr(out), s), "disco_gcn_norm_csr_f32")
+    return rowptr, c32.to(torch.int64), out

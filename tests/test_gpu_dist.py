@@ -91,3 +91,50 @@ def test_sharded_edge_construction_equals_single_gpu(tmp_path):
         for r in range(world):
             ei, ew = torch.load(tmp_path / f"{variant}{r}.pt", weights_only=True)
             assert torch.equal(ei, ref_ei) and torch.equal(ew, ref_ew), (variant, r)
+
+
+def _norm_worker(rank, world, port, n, with_loop0, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disco_amd import SparseTensor, utils
+        from disco_amd.dist import balanced_row_offsets, normalize_adj_partition
+        dev = torch.device("cuda", 0)
+        rowptr, col, val = _norm_graph(n, with_loop0)
+        offs = balanced_row_offsets(torch.from_numpy(rowptr), world)
+        lo, hi = offs[rank], offs[rank + 1]
+        sl = slice(rowptr[lo], rowptr[hi])
+        rp, c, v = normalize_adj_partition(torch.from_numpy(rowptr[lo:hi + 1] - rowptr[lo]).to(dev), torch.from_numpy(col[sl]).to(dev),
+                                           torch.from_numpy(val[sl]).to(dev), offs, rank, world)
+        torch.save((rp.cpu(), c.cpu(), v.cpu(), lo, hi), os.path.join(result_dir, f"n{rank}.pt"))
+        if rank == 0:
+            adj = SparseTensor(rowptr=torch.from_numpy(rowptr).to(dev), col=torch.from_numpy(col).to(dev),
+                               value=torch.from_numpy(val).to(dev), sparse_sizes=(n, n), is_sorted=True)
+            g = utils.normalize_adj_csr(adj)
+            torch.save(tuple(t.cpu() for t in g.csr()), os.path.join(result_dir, "single.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _norm_graph(n, with_loop0):
+    rowptr, col, val = random_csr(n, n, 7, seed=91, hubs=[(5, 700)], weighted=True)
+    val = np.abs(val) + 0.1
+    has = col[rowptr[0]:rowptr[1]].min() == 0 if rowptr[1] > rowptr[0] else False
+    if with_loop0 and not has:          # give node 0 a self-loop: no identity is added, float32 mode
+        col[rowptr[0]] = 0
+    if not with_loop0 and has:
+        val[rowptr[0]] = 0.0            # an explicit zero at (0,0) counts as "no self-loop" (mx[0,0] == 0)
+    return rowptr, col, val
+
+
+@pytest.mark.parametrize("with_loop0", [False, True])
+def test_partitioned_normalize_adj_bitwise_equals_single_gpu(with_loop0, tmp_path):
+    n, world = 2500, 2
+    mp.spawn(_norm_worker, args=(world, _free_port(), n, with_loop0, str(tmp_path)), nprocs=world, join=True)
+    rp, col, val = torch.load(tmp_path / "single.pt", weights_only=True)
+    for r in range(world):
+        prp, pc, pv, lo, hi = torch.load(tmp_path / f"n{r}.pt", weights_only=True)
+        b, e = int(rp[lo]), int(rp[hi])
+        assert torch.equal(prp, rp[lo:hi + 1] - rp[lo])
+        assert torch.equal(pc, col[b:e]) and torch.equal(pv, val[b:e])
