@@ -19,8 +19,19 @@
 
 namespace disco {
 
-constexpr int64_t kDefaultHubThreshold = 2048;
-constexpr int64_t kDefaultHubPiece = 8192;
+// Defaults (hub_threshold = 0 / hub_piece = 0).  One lane group walks a non-hub row serially at ~10 entries
+// per microsecond, so the longest such row bounds the launch: on a small graph (ogbn-arxiv, 0.1 ms per hop) a
+// 2048-entry row alone is 0.2 ms.  Threshold = nnz / 4096 rounded down to a power of two, clamped to
+// [256, 2048]; piece = 4 x threshold clamped to [1024, 8192]  (profiles/r1/tune_hub_defaults.log).
+static inline int64_t default_hub_threshold(int64_t nnz) {
+  int64_t t = 256;
+  while (t * 2 <= nnz / 4096 && t < 2048) t *= 2;
+  return t;
+}
+static inline int64_t default_hub_piece(int64_t threshold) {
+  int64_t p = 4 * threshold;
+  return p < 1024 ? 1024 : (p > 8192 ? 8192 : p);
+}
 
 struct Counters {
   unsigned long long n_hub;
@@ -173,8 +184,8 @@ using namespace disco;
 extern "C" size_t disco_schedule_workspace_bytes(int64_t n_rows, int64_t nnz, int64_t hub_threshold, int64_t hub_piece) {
   if (n_rows < 0 || nnz < 0) return 0;
   if (hub_threshold < 0) hub_threshold = -hub_threshold;
-  int64_t T = hub_threshold > 0 ? hub_threshold : kDefaultHubThreshold;
-  int64_t P = hub_piece > 0 ? hub_piece : kDefaultHubPiece;
+  int64_t T = hub_threshold > 0 ? hub_threshold : default_hub_threshold(nnz);
+  int64_t P = hub_piece > 0 ? hub_piece : default_hub_piece(T);
   Layout L;
   if (make_layout(n_rows, nnz, T, P, L) != DISCO_OK) return 0;
   return (size_t)L.total;
@@ -187,8 +198,8 @@ extern "C" int disco_schedule_build(const int64_t* rowptr, int64_t n_rows, int64
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   int natural = 0;
   if (hub_threshold < 0) { natural = 1; hub_threshold = -hub_threshold; }  // negative threshold: keep natural row order
-  int64_t T = hub_threshold > 0 ? hub_threshold : kDefaultHubThreshold;
-  int64_t P = hub_piece > 0 ? hub_piece : kDefaultHubPiece;
+  int64_t T = hub_threshold > 0 ? hub_threshold : default_hub_threshold(nnz);
+  int64_t P = hub_piece > 0 ? hub_piece : default_hub_piece(T);
   if (P < 64) P = 64;
   Layout L;
   int rc = make_layout(n_rows, nnz, T, P, L);

@@ -24,7 +24,7 @@ WIN_COLS = 128           # column block width of the windowed launches (libdisco
 WINDOW_BYTES = 6 << 20   # measured optimum on MI355X (4 MiB L2 per XCD): fewer, slightly over-sized windows win
 
 
-WIN_HUB_THRESHOLD, WIN_HUB_PIECE = 8192, 16384   # hub split used with windowed launches (tune_hub_windowed.log)
+WIN_HUB_THRESHOLD, WIN_HUB_PIECE = 8192, 4096   # hub split used with windowed launches (tune_hub_windowed.log)
 
 
 def sweep_window_rows(feat: int, window_bytes: int = WINDOW_BYTES, cap: int = WIN_COLS) -> int:

@@ -109,8 +109,12 @@ def test_schedule_and_natural_order_agree(sched):
     assert_fwd_close(y, y64, bound)
     if sched:
         ws, info = adj.schedule()
-        assert info.n_hub_rows == 2 and info.n_multi_rows == 1 and info.max_row_nnz == 30000
-        assert info.n_hub_pieces == 1 + info.n_hub_partials and info.n_hub_partials == 4
+        # small graph: default threshold 256, pieces of <= 1024 entries -> 30 + 3 pieces, both rows multi-piece
+        assert info.hub_threshold == 256 and info.hub_piece == 1024
+        assert info.n_hub_rows == 2 and info.n_multi_rows == 2 and info.max_row_nnz == 30000
+        assert info.n_hub_pieces == info.n_hub_partials == 33
+        ws2, info2 = to_adj(rowptr, col, val, 2000).schedule(2048, 8192)
+        assert info2.n_hub_rows == 2 and info2.n_multi_rows == 1 and info2.n_hub_pieces == 1 + info2.n_hub_partials == 5
         # deterministic: two launches give identical bits
         y2 = ops.spmm_raw(adj, torch.from_numpy(x).to(dev()), "sum").cpu().numpy()
         assert np.array_equal(y, y2)
