@@ -17,6 +17,8 @@ struct Tuning {
   int win_cols = 0;   // column block width of the windowed launches (0 = 128)
   int win_rows_per_group = 0;  // consecutive rows one lane group handles per windowed launch (0 = 1)
   int sweep_blocks_per_cu = 0;  // 0 = 4
+  int psync_pct = 0;  // sweep_mode 3: share of a sync group's waves a wave waits for (0 = 100)
+  int psync_polls = 0;  // sweep_mode 3: polls before a wave gives up waiting (0 = 256)
   int addr24 = 1;     // 0 = always 64-bit gather addressing
 };
 

@@ -144,6 +144,8 @@ extern "C" int disco_set_tuning(const char* key, int64_t value) {
   else if (!strcmp(key, "win_rpg")) t.win_rows_per_group = (int)value;
   else if (!strcmp(key, "sweep_blocks_per_cu")) t.sweep_blocks_per_cu = (int)value;
   else if (!strcmp(key, "addr24")) t.addr24 = (int)value;
+  else if (!strcmp(key, "psync_pct")) t.psync_pct = (int)value;
+  else if (!strcmp(key, "psync_polls")) t.psync_polls = (int)value;
   else return DISCO_EINVAL;
   return DISCO_OK;
 }

@@ -532,6 +532,116 @@ __global__ __launch_bounds__(256, 4) void k_spmm_sweep(const int64_t* __restrict
   }
 }
 
+// ---- synchronised persistent windows (sweep_mode 3, experimental) --------------------------------------
+// Same windows as k_spmm_rows_win, but ONE launch per column block: every lane group keeps R output rows in
+// registers and walks the windows itself, so the y block is written once instead of being read-modified-
+// written per window.  What the launch boundary did for k_spmm_rows_win -- keeping all waves inside one
+// window -- is done by pacing flags: a workgroup that finishes window w publishes the step number and polls
+// until `target` workgroups of its sync group (same blockIdx % 8, i.e. the same XCD under round-robin
+// dispatch) have done so, giving up after `poll_cap` polls.  The flags only PACE the
+// waves: no data depends on them, every wait is bounded, so neither correctness nor termination can depend
+// on co-residency or on the dispatch order.  Rows are dealt round-robin over the groups in the degree-sorted
+// order, so all groups carry the same mix of row lengths.  Entries are visited in CSR order: same bits.
+constexpr int PSYNC_GROUPS = 8;
+constexpr int64_t PSYNC_BYTES = 1 << 20;       // flag area at the end of the sweep workspace
+
+// One flag word per workgroup (no read-modify-write, no shared hot word): after window step `s` a workgroup
+// stores s + 1 into its own flag; wave 0 then polls the flags of its sync group (contiguous in memory)
+// until `target` of them have reached s + 1, at most `poll_cap` times.
+__device__ __forceinline__ void window_pace(int* flags, int sg, int members, int me, int step, int target, int poll_cap) {
+  __syncthreads();                       // all four waves of this workgroup are done with the window
+  if (threadIdx.x < 64) {
+    int* grp = flags + (int64_t)sg * members;
+    if (threadIdx.x == 0) __hip_atomic_store(grp + me, step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int polls = 0; polls < poll_cap; ++polls) {
+      int done = 0;
+      for (int base = 0; base < members; base += 64) {
+        const int j = base + (int)threadIdx.x;
+        const int f = j < members ? __hip_atomic_load(grp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        done += __popcll(__ballot(j < members && f > step));
+      }
+      if (done >= target) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+}
+
+template <int VEC, int G, bool HASVAL, bool A24>
+__global__ __launch_bounds__(256) void k_spmm_psync(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                    const float* __restrict__ val, const float* __restrict__ x,
+                                                    int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
+                                                    const uint32_t* __restrict__ perm, int64_t first, int64_t count,
+                                                    const uint32_t* __restrict__ wptr, int64_t cp, int P, int flags,
+                                                    int n_iter, int* __restrict__ prog, int target, int poll_cap) {
+  typedef typename Vec<VEC>::type V;
+  constexpr int R = 8;
+  constexpr int RPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int gl = lane % G;
+  const int64_t total_groups = (int64_t)gridDim.x * 4 * RPW;
+  const int64_t ggrp = ((int64_t)blockIdx.x * 4 + wave) * RPW + lane / G;
+  const int sg = blockIdx.x % PSYNC_GROUPS;
+  int64_t off[1];
+  lane_offsets<VEC, G, 1>(nvec, gl, off);
+  for (int it = 0; it < n_iter; ++it) {
+    // lane r < R of a group carries the table entries of the group's row slot r
+    const int64_t pos = ((int64_t)it * R + (gl < R ? gl : 0)) * total_groups + ggrp;
+    const bool valid = gl < R && pos < count;
+    uint32_t cur = valid ? wptr[pos] : 0u;
+    const uint32_t rowid = valid ? perm[first + pos] : 0u;
+    V acc[R][1];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r][0] = 0.0f;
+    for (int w = 0; w < P; ++w) {
+      const uint32_t nxt = valid ? wptr[(int64_t)(w + 1) * cp + pos] : cur;
+      // the first (col, val) batch of all R segments is requested up front: one memory latency per window
+      // instead of one per row (prefetching it one window ahead as well costs a wave of occupancy and loses)
+      int cvs[R]; float wvs[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t b = (uint32_t)__shfl((int)cur, r, G);
+        const uint32_t e = (uint32_t)__shfl((int)nxt, r, G);
+        cvs[r] = 0; wvs[r] = 0.0f;
+        if ((uint32_t)gl < e - b) {
+          cvs[r] = col[(int64_t)b + gl];
+          if constexpr (HASVAL) wvs[r] = val[(int64_t)b + gl];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t b = (uint32_t)__shfl((int)cur, r, G);
+        const uint32_t e = (uint32_t)__shfl((int)nxt, r, G);
+        if (e != b) {
+          const uint32_t len = e - b;
+          const int n0 = len < (uint32_t)G ? (int)len : G;
+          consume_batch<VEC, G, 1, OP_SUM, HASVAL, A24>(cvs[r], wvs[r], n0, x, ldx, off, acc[r]);
+          if (len > (uint32_t)G)
+            accumulate_range<VEC, G, 1, OP_SUM, HASVAL, A24>((int64_t)b + G, (int64_t)e, col, val, x, ldx, nvec, gl, acc[r]);
+        }
+      }
+      cur = nxt;
+      if (w + 1 < P) window_pace(prog, sg, (int)(gridDim.x / PSYNC_GROUPS), (int)(blockIdx.x / PSYNC_GROUPS), it * P + w, target, poll_cap);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool ok = __shfl((int)valid, r, G) != 0;
+      const int64_t row = (int64_t)(uint32_t)__shfl((int)rowid, r, G);
+      if (ok && gl < nvec) {
+        V a = acc[r][0];
+        V* dst = reinterpret_cast<V*>(y + row * ldy + (int64_t)gl * VEC);
+        if (flags & FLAG_MEAN) {
+          const float cnt = (float)(rowptr[row + 1] - rowptr[row]);
+          if (cnt > 0.0f) a = vdiv<VEC>(a, cnt);
+        }
+        if (flags & FLAG_ACCUM) a = *dst + a;
+        *dst = a;
+      }
+    }
+  }
+}
+
 // wptr[w][pos] for w in [0, P]: lower bound of w * window_rows among the (sorted) columns of row perm[first+pos]
 __global__ __launch_bounds__(256) void k_build_wptr(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                     const uint32_t* __restrict__ perm, int64_t first, int64_t count,
@@ -600,9 +710,42 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
     }
   }
   bool swept = false;
+  if constexpr (OP == OP_SUM && VEC == 4 && NV == 1) {
+    if (count > 0 && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && tuning().sweep_mode == 3) {
+      const disco_schedule_info& s = *a.info;
+      const uint32_t* wptr = reinterpret_cast<const uint32_t*>(s.sweep_ws);
+      const int P = (int)s.sweep_windows;
+      constexpr int R = 8;
+      int per_cu = 0;
+      hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_spmm_psync<VEC, G, HASVAL, A24>), 256, 0);
+      if (oe != hipSuccess) { set_last_hip_error((int)oe); return DISCO_EHIP; }
+      if (tuning().sweep_blocks_per_cu > 0 && tuning().sweep_blocks_per_cu < per_cu) per_cu = tuning().sweep_blocks_per_cu;
+      int64_t blocks = (int64_t)device_cus() * (per_cu > 0 ? per_cu : 1);
+      const int64_t want = (count + 4 * RPW * R - 1) / (4 * RPW * R);
+      if (blocks > want) blocks = want;
+      blocks = blocks / PSYNC_GROUPS * PSYNC_GROUPS;
+      if (blocks >= PSYNC_GROUPS) {
+        const int64_t per_iter = blocks * 4 * RPW * R;
+        const int n_iter = (int)((count + per_iter - 1) / per_iter);
+        if (blocks * 4 <= PSYNC_BYTES) {
+          int* prog = reinterpret_cast<int*>(const_cast<char*>(static_cast<const char*>(s.sweep_ws)) +
+                                             (size_t)(P + 1) * s.sweep_count_padded * sizeof(uint32_t));
+          hipError_t me = hipMemsetAsync(prog, 0, (size_t)(blocks * 4), a.stream);
+          if (me != hipSuccess) { set_last_hip_error((int)me); return DISCO_EHIP; }
+          const int pct = tuning().psync_pct > 0 ? tuning().psync_pct : 100;
+          const int target = (int)((blocks / PSYNC_GROUPS) * pct / 100);
+          const int cap = tuning().psync_polls > 0 ? tuning().psync_polls : 256;
+          hipLaunchKernelGGL((k_spmm_psync<VEC, G, HASVAL, A24>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
+                             a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, wptr, s.sweep_count_padded, P, mean,
+                             n_iter, prog, target, cap);
+          swept = true;
+        }
+      }
+    }
+  }
   if constexpr (OP == OP_SUM && (VEC == 4 || VEC == 2)) {
     // windowed launches (L2-blocked): mean of an accumulating call is not meaningful, so SUM_ACC + MEAN never meet
-    if (count > 0 && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && tuning().sweep_mode == 2) {
+    if (!swept && count > 0 && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && tuning().sweep_mode >= 2) {
       const disco_schedule_info& s = *a.info;
       const uint32_t* wptr = reinterpret_cast<const uint32_t*>(s.sweep_ws);
       const int P = (int)s.sweep_windows;
@@ -746,7 +889,7 @@ extern "C" size_t disco_sweep_workspace_bytes(const disco_schedule_info* info, i
   if (count <= 0) return 0;
   const int64_t cp = (count + 15) / 16 * 16;
   const int64_t P = (n_cols + window_rows - 1) / window_rows;
-  return (size_t)((P + 1) * cp) * sizeof(uint32_t) + 256;
+  return (size_t)((P + 1) * cp) * sizeof(uint32_t) + 256 + (size_t)PSYNC_BYTES;   // table + pacing counters (sweep_mode 3)
 }
 
 extern "C" int disco_sweep_build(const int64_t* rowptr, const int32_t* col, const void* sched_ws, disco_schedule_info* info,

@@ -212,7 +212,7 @@ def test_full_size_properties_arxiv_shaped():
 
 @pytest.mark.parametrize("F", [64, 128, 602])
 @pytest.mark.parametrize("reduce", ["sum", "mean"])
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_sweep_kernel_same_bits_as_plain(F, reduce, mode):
     """The L2-blocked variants (1 = persistent sweep kernel, 2 = windowed launches) visit each row's entries
     in CSR order: same bits as the plain kernel on the rows they own (all rows below the hub threshold)."""

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--mode", default="2", help="comma list: 1 = persistent sweep kernel, 2 = windowed launches")
     ap.add_argument("--rpg", default="4", help="comma list: rows per lane group per windowed launch")
     ap.add_argument("--wincols", default="128", help="comma list: column block width of the windowed launches")
+    ap.add_argument("--pct", default="100", help="comma list: sweep_mode 3 pacing threshold (percent of the sync group)")
+    ap.add_argument("--polls", default="256", help="comma list: sweep_mode 3 poll cap")
     ap.add_argument("--addr24", default="1", help="comma list of 0/1: 24-bit gather addressing")
     ap.add_argument("--ncols", type=int, default=0, help="gather from a table of this many rows (rectangular, unnormalised)")
     args = ap.parse_args()
@@ -77,10 +79,12 @@ def main():
                                     for wkb in ([int(v) for v in args.window_kb.split(",")] if sw else [0]):
                                         for bpc in ([int(v) for v in args.bpc.split(",")] if sw else [0]):
                                             for mode in ([int(v) for v in args.mode.split(",")] if sw else [0]):
-                                                for wc in ([int(v) for v in args.wincols.split(",")] if sw and mode == 2 else [0]):
-                                                    for rpg in ([int(v) for v in args.rpg.split(",")] if sw and mode == 2 else [0]):
+                                                for wc in ([int(v) for v in args.wincols.split(",")] if sw and mode >= 2 else [0]):
+                                                    for rpg in ([int(v) for v in args.rpg.split(",")] if sw and mode >= 2 else [0]):
                                                         for a24 in [int(v) for v in args.addr24.split(",")]:
-                                                            variants.append(dict(ld=ld, lib=libname, order=order, hub=hub, force=force, maxvec=mv,
+                                                          for pct in ([int(v) for v in args.pct.split(",")] if mode == 3 else [0]):
+                                                           for polls in ([int(v) for v in args.polls.split(",")] if mode == 3 else [0]):
+                                                            variants.append(dict(pct=pct, polls=polls, ld=ld, lib=libname, order=order, hub=hub, force=force, maxvec=mv,
                                                                                  slices=s, sweep=sw, wkb=wkb, bpc=bpc, mode=mode, wc=wc, rpg=rpg, a24=a24))
 
     bufs = {}
@@ -126,6 +130,8 @@ def main():
             lib.disco_set_tuning(b"win_cols", v["wc"])
             lib.disco_set_tuning(b"win_rpg", v["rpg"])
             lib.disco_set_tuning(b"addr24", v["a24"])
+            lib.disco_set_tuning(b"psync_pct", v["pct"])
+            lib.disco_set_tuning(b"psync_polls", v["polls"])
             if v["force"] == "auto":
                 lib.disco_set_tuning(b"force_g", 0)
                 lib.disco_set_tuning(b"force_nv", 0)
