@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ r
 // in CSR order: the only difference to k_spmm_rows is that the running sum passes through memory (no
 // rounding: float32 in, float32 out) -- same bits.
 template <int VEC, int G, int NV, bool HASVAL, bool A24>
-__global__ __launch_bounds__(256) void k_spmm_rows_win(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+__global__ __launch_bounds__(256, NV == 1 ? 6 : 1) void k_spmm_rows_win(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                        const float* __restrict__ val, const float* __restrict__ x,
                                                        int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
                                                        const uint32_t* __restrict__ perm, int64_t first, int64_t count,
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_spmm_rows_win(const int64_t* __restrict
   // A group handles up to MAXR consecutive rows (positions) per launch, software-pipelined: all their
   // table entries are fetched first, then the first (col, val) batch and the y block of row i+1 are in
   // flight while row i gathers -- the per-row chain table -> (col, y) -> gather overlaps across rows.
-  constexpr int MAXR = 4;
+  constexpr int MAXR = 2;
   const int64_t grp0 = (((int64_t)blockIdx.x * 4 + wave) * RPW + lane / G) * rpg;
   if (grp0 >= count) return;
   int64_t rem_rows = count - grp0;
@@ -750,7 +750,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       const uint32_t* wptr = reinterpret_cast<const uint32_t*>(s.sweep_ws);
       const int P = (int)s.sweep_windows;
       int rpg = tuning().win_rows_per_group > 0 ? tuning().win_rows_per_group : 2;
-      if (rpg > 4) rpg = 4;
+      if (rpg > 2) rpg = 2;
       int64_t blocks = (count + 4 * RPW * rpg - 1) / (4 * RPW * rpg);
       if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
       for (int w = 0; w < P; ++w) {
