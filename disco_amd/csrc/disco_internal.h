@@ -13,9 +13,9 @@ struct Tuning {
   int force_g = 0;    // 0 = automatic
   int force_nv = 0;   // 0 = automatic
   int max_vec = 0;    // 0 = 4
-  int sweep_mode = 2; // with a sweep structure attached: 0 = ignore it, 1 = persistent sweep kernel, 2 = windowed launches
+  int sweep_mode = 2; // with a window table attached: 0 = ignore it, 1 = persistent sweep, 2 = windowed launches, 3 = paced persistent windows
   int win_cols = 0;   // column block width of the windowed launches (0 = 128)
-  int win_rows_per_group = 0;  // consecutive rows one lane group handles per windowed launch (0 = 1)
+  int win_rows_per_group = 0;  // consecutive rows one lane group handles per windowed launch (0 = 2, at most 2)
   int sweep_blocks_per_cu = 0;  // 0 = 4
   int psync_pct = 0;  // sweep_mode 3: share of a sync group's waves a wave waits for (0 = 100)
   int psync_polls = 0;  // sweep_mode 3: polls before a wave gives up waiting (0 = 256)

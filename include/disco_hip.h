@@ -203,7 +203,11 @@ int disco_sym_threshold_fill(const float* S, int64_t n, int64_t lds, float thres
                              const int64_t* rowstart, int64_t E, int64_t* edge_index,
                              float* edge_weight, void* stream);
 
-/* Benchmark / test knobs ("force_g", "force_nv", "max_vec", "sweep_mode", "win_cols", "sweep_blocks_per_cu"). */
+/* Benchmark / test knobs: "force_g", "force_nv", "max_vec" (lane-group shape), "sweep_mode" (with a window table
+ * attached: 0 ignore it, 1 persistent sweep, 2 windowed launches [default], 3 paced persistent windows),
+ * "win_cols" (column block of modes 2/3, default 128), "win_rpg" (rows per lane group and launch, 1 or 2),
+ * "sweep_blocks_per_cu", "psync_pct", "psync_polls" (mode 3 pacing), "addr24" (0 = always 64-bit gather
+ * addresses).  Unknown keys return DISCO_EINVAL. */
 int disco_set_tuning(const char* key, int64_t value);
 
 /* ---- CSR construction from raw COO edges ---------------------------------------------
