@@ -21,6 +21,9 @@ Tuning& tuning() { static Tuning t; return t; }
 //                    utils.py:426-427); 16 lanes per row, fixed-order tree.
 // add_identity == 0: scipy keeps the float32 matrix in float32 all the way (utils.py:427-432), and its
 //                    row sum is a sequential float32 accumulation in CSR order: one lane per row.
+constexpr int64_t kLongRow = 4096;
+constexpr long long kLongMarker = 0x7ff8d15c0d15c000LL;   // a quiet NaN payload
+
 __global__ __launch_bounds__(256) void k_csr_rowsum(const int64_t* __restrict__ rowptr, const float* __restrict__ val,
                                                     int64_t n_rows, int add_identity, double* __restrict__ out) {
   const int gl = threadIdx.x & 15;
@@ -37,11 +40,44 @@ __global__ __launch_bounds__(256) void k_csr_rowsum(const int64_t* __restrict__ 
     return;
   }
   double s = 0.0;
+  if (val && e - b > kLongRow) {
+    // a 16-lane group would walk a hub row (ogbn-products: 600 k entries) for milliseconds: mark it for
+    // k_csr_rowsum_long (the marker is a NaN with a fixed payload, which no sum of finite inputs produces)
+    if (gl == 0) out[row] = __longlong_as_double(kLongMarker);
+    return;
+  }
   if (val) { for (int64_t i = b + gl; i < e; i += 16) s += (double)val[i]; }
   for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
   if (!val) s = (double)(e - b);
   s += 1.0;  // mx + I (utils.py:426): every row sum grows by one
   if (row < n_rows && gl == 0) out[row] = s;
+}
+
+// rows marked by k_csr_rowsum: the whole workgroup sums one row (256 strided float64 partials, LDS tree in
+// a fixed order); a workgroup scans the 256 rows it owns for markers.
+__global__ __launch_bounds__(256) void k_csr_rowsum_long(const int64_t* __restrict__ rowptr, const float* __restrict__ val,
+                                                         int64_t n_rows, double* __restrict__ out) {
+  __shared__ double part[256];
+  __shared__ int marked[256];
+  const int64_t r0 = (int64_t)blockIdx.x * 256;
+  const int64_t mine = r0 + threadIdx.x;
+  marked[threadIdx.x] = mine < n_rows && __double_as_longlong(out[mine]) == kLongMarker;
+  __syncthreads();
+  for (int k = 0; k < 256; ++k) {
+    if (!marked[k]) continue;                    // uniform: read from LDS
+    const int64_t row = r0 + k;
+    const int64_t b = rowptr[row], e = rowptr[row + 1];
+    double s = 0.0;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) s += (double)val[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[row] = part[0] + 1.0;
+    __syncthreads();
+  }
 }
 
 __global__ __launch_bounds__(256) void k_inv_sqrt_norm(double* __restrict__ d, int64_t n, int add_identity) {
@@ -55,15 +91,32 @@ __global__ __launch_bounds__(256) void k_inv_sqrt_norm(double* __restrict__ d, i
   d[i] = r;
 }
 
+// Entry-parallel: a workgroup owns a chunk of kScaleChunk consecutive entries, finds the rows its chunk
+// touches with one binary search per end and each entry's row with a short search inside that range -- the
+// work per workgroup does not depend on row lengths (a row-per-lane-group version spent 30 ms on the one
+// 600 k-entry row of ogbn-products).
+constexpr int kScaleChunk = 2048;
+__device__ __forceinline__ int64_t row_of_entry(const int64_t* __restrict__ rowptr, int64_t lo, int64_t hi, int64_t i) {
+  // largest r in [lo, hi] with rowptr[r] <= i
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (rowptr[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 __global__ __launch_bounds__(256) void k_gcn_scale_csr(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                       const float* __restrict__ vin, int64_t n_rows, int add_identity,
-                                                       const double* __restrict__ r, float* __restrict__ vout) {
-  const int gl = threadIdx.x & 15;
-  int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-  if (row >= n_rows) return;
-  const int64_t b = rowptr[row], e = rowptr[row + 1];
-  const double rr = r[row];
-  for (int64_t i = b + gl; i < e; i += 16) {
+                                                       const float* __restrict__ vin, int64_t n_rows, int64_t nnz,
+                                                       int add_identity, const double* __restrict__ r,
+                                                       float* __restrict__ vout) {
+  const int64_t c0 = (int64_t)blockIdx.x * kScaleChunk;
+  const int64_t c1 = c0 + kScaleChunk < nnz ? c0 + kScaleChunk : nnz;
+  if (c0 >= c1) return;
+  const int64_t r_lo = row_of_entry(rowptr, 0, n_rows - 1, c0);
+  const int64_t r_hi = row_of_entry(rowptr, r_lo, n_rows - 1, c1 - 1);
+  for (int64_t i = c0 + threadIdx.x; i < c1; i += 256) {
+    const int64_t row = row_of_entry(rowptr, r_lo, r_hi, i);
+    const double rr = r[row];
     const int64_t c = col[i];
     if (add_identity) {
       double v = vin ? (double)vin[i] : 1.0;
@@ -157,6 +210,9 @@ extern "C" int disco_csr_rowsum_f64(const int64_t* rowptr, const float* val, int
   if (!rowptr || !rowsum) return DISCO_EINVAL;
   hipLaunchKernelGGL(k_csr_rowsum, dim3(blocks_for(n_rows, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr,
                      val, n_rows, add_identity, rowsum);
+  if (add_identity && val)
+    hipLaunchKernelGGL(k_csr_rowsum_long, dim3(blocks_for(n_rows, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr,
+                       val, n_rows, rowsum);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
 }
@@ -168,8 +224,13 @@ extern "C" int disco_gcn_norm_csr_f32(const int64_t* rowptr, const int32_t* col,
   if (!rowptr || !col || !rowsum || !val_out) return DISCO_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(k_inv_sqrt_norm, dim3(blocks_for(n_rows, 256)), dim3(256), 0, s, rowsum, n_rows, add_identity);
-  hipLaunchKernelGGL(k_gcn_scale_csr, dim3(blocks_for(n_rows, 16)), dim3(256), 0, s, rowptr, col, val_in, n_rows,
-                     add_identity, (const double*)rowsum, val_out);
+  int64_t nnz = 0;   // rowptr lives on the device: the entry count is its last element
+  DISCO_HIP_TRY(hipMemcpyAsync(&nnz, rowptr + n_rows, sizeof(nnz), hipMemcpyDeviceToHost, s));
+  DISCO_HIP_TRY(hipStreamSynchronize(s));
+  if (nnz < 0 || (nnz + kScaleChunk - 1) / kScaleChunk > 0x7fffffffLL) return DISCO_EINVAL;
+  if (nnz > 0)
+    hipLaunchKernelGGL(k_gcn_scale_csr, dim3((unsigned)((nnz + kScaleChunk - 1) / kScaleChunk)), dim3(256), 0, s, rowptr, col,
+                       val_in, n_rows, nnz, add_identity, (const double*)rowsum, val_out);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
 }

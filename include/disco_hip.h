@@ -148,7 +148,8 @@ int disco_csr_rowsum_f64(const int64_t* rowptr, const float* val, int64_t n_rows
                          double* rowsum, void* stream);
 /* r = rowsum^-1/2 with inf -> 0 (utils.py:428-429), then val_out[e] = r[row] * val_in[e] * r[col[e]]
  * (utils.py:430-432) in the arithmetic described above.  `rowsum` is overwritten with r.
- * val_in NULL = all 1; val_out may alias val_in. */
+ * val_in NULL = all 1; val_out may alias val_in.  Entry-parallel (independent of row lengths); reads
+ * rowptr[n_rows] back to size the launch, i.e. synchronises the stream once (a set-up call). */
 int disco_gcn_norm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val_in,
                            int64_t n_rows, int add_identity, double* rowsum, float* val_out,
                            void* stream);
