@@ -130,9 +130,33 @@ __global__ __launch_bounds__(256) void k_gcn_scale_csr(const int64_t* __restrict
 }
 
 // ---- edge-index branch ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_degree_count(const int64_t* __restrict__ idx, int64_t E, unsigned int* __restrict__ cnt) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < E) atomicAdd(&cnt[idx[i]], 1u);  // integer counts: exact and order independent
+// Integer counts: exact and order independent.  A power-law graph sends a large share of its edges to a few
+// hub nodes, and same-address global atomics serialise (7.2 ms for 52 M edges, ogbn-products shape), so each
+// workgroup first counts into a small LDS table keyed by node (first come, first served: hubs, being
+// frequent, claim their slots early); edges that lose the slot go to the global counter directly, the
+// table is flushed with one global atomic per occupied slot.  Out-of-range ids are ignored.
+constexpr int kDegSlots = 2048;
+constexpr int kDegChunk = 16384;   // edges per workgroup
+__global__ __launch_bounds__(256) void k_degree_count(const int64_t* __restrict__ idx, int64_t E, int64_t N,
+                                                      unsigned int* __restrict__ cnt) {
+  __shared__ long long keys[kDegSlots];
+  __shared__ unsigned int vals[kDegSlots];
+  for (int h = threadIdx.x; h < kDegSlots; h += 256) { keys[h] = -1; vals[h] = 0u; }
+  __syncthreads();
+  const int64_t c0 = (int64_t)blockIdx.x * kDegChunk;
+  const int64_t c1 = c0 + kDegChunk < E ? c0 + kDegChunk : E;
+  for (int64_t i = c0 + threadIdx.x; i < c1; i += 256) {
+    const long long k = idx[i];
+    if (k < 0 || k >= N) continue;
+    const unsigned int h = ((unsigned int)k * 2654435761u) >> 21;          // 11 bits
+    const long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]), (unsigned long long)-1LL,
+                                     (unsigned long long)k);
+    if (prev == -1 || prev == k) atomicAdd(&vals[h], 1u);
+    else atomicAdd(&cnt[k], 1u);
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < kDegSlots; h += 256)
+    if (vals[h]) atomicAdd(&cnt[keys[h]], vals[h]);
 }
 
 __global__ __launch_bounds__(256) void k_u32_to_f32(float* __restrict__ d, int64_t n) {
@@ -241,7 +265,7 @@ extern "C" int disco_degree_count_f32(const int64_t* idx, int64_t E, int64_t N, 
   if (!deg || (E > 0 && !idx)) return DISCO_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   DISCO_HIP_TRY(hipMemsetAsync(deg, 0, sizeof(float) * (size_t)N, s));
-  if (E > 0) hipLaunchKernelGGL(k_degree_count, dim3(blocks_for(E, 256)), dim3(256), 0, s, idx, E, reinterpret_cast<unsigned int*>(deg));
+  if (E > 0) hipLaunchKernelGGL(k_degree_count, dim3(blocks_for(E, kDegChunk)), dim3(256), 0, s, idx, E, N, reinterpret_cast<unsigned int*>(deg));
   hipLaunchKernelGGL(k_u32_to_f32, dim3(blocks_for(N, 256)), dim3(256), 0, s, deg, N);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
