@@ -210,6 +210,49 @@ def test_full_size_properties_arxiv_shaped():
     assert_fwd_close(y1[rows], y64, bound, what="arxiv-shaped sample")
 
 
+def test_full_size_properties_reddit_shaped():
+    """BASELINE config 2 (Reddit shape: N = 232 965, nnz = 114.5 M, F = 602) at full size, the bench workload,
+    on the default (windowed, L2-blocked) path: linearity, A*1 == row sums, the windowed result has the same
+    bits as the plain kernel on every non-hub row, and a 512-row sample agrees with the float64 oracle."""
+    from disco_amd import SparseTensor, graphgen, ops, utils
+    spec = graphgen.SPECS["reddit"]
+    n, F = spec.n_nodes, spec.feat
+    row, col = graphgen.powerlaw_edges(n, spec.nnz, spec.skew, spec.seed, device=dev())
+    adj = utils.normalize_adj_csr(SparseTensor(row=row, col=col, value=None, sparse_sizes=(n, n), is_sorted=True))
+    del row, col
+    x = graphgen.features(n, F, spec.seed, device=dev(), ld=608)
+    z = graphgen.features(n, F, spec.seed + 1, device=dev(), ld=608)
+    ws, info = adj.schedule(feat=F)
+    assert info.sweep_ws and info.sweep_windows >= 2, "the Reddit shape must take the windowed path"
+    y = ops.spmm_raw(adj, x, "sum")
+    yz = ops.spmm_raw(adj, z, "sum")
+    ylin = ops.spmm_raw(adj, 0.5 * x - 2.0 * z, "sum")
+    scale = ops.spmm_raw(adj, x.abs() + 2 * z.abs(), "sum")          # weights are positive
+    assert bool(((ylin - (0.5 * y - 2.0 * yz)).abs() <= 2e-5 * scale + 1e-30).all())
+    del yz, ylin, scale, z
+    rs = torch.zeros(n, dtype=torch.float64, device=dev()).index_add_(0, adj.storage.row(), adj.storage.value().double())
+    a1 = ops.spmm_raw(adj, torch.ones(n, 4, device=dev()), "sum")[:, 0].double()
+    assert bool(((a1 - rs).abs() <= 1e-5 * rs.abs() + 1e-12).all())
+    # same bits as the plain kernel (same hub split) on the rows the windowed kernel owns
+    plain = adj.set_value(adj.storage.value())
+    plain._sched, plain._sweep = None, None
+    ws_p, info_p = plain.schedule(int(info.hub_threshold), int(info.hub_piece), feat=F, sweep=False)
+    assert not info_p.sweep_ws
+    y_plain = ops.spmm_raw(plain, x, "sum")
+    deg = adj.storage.rowptr()[1:] - adj.storage.rowptr()[:-1]
+    keep = deg <= int(info.hub_threshold)
+    assert int((~keep).sum()) == int(info.n_hub_rows) > 0
+    assert torch.equal(y[keep], y_plain[keep])
+    # sample against the float64 oracle
+    rp, c, v = (t.cpu().numpy() for t in adj.csr())
+    rows = np.sort(np.random.default_rng(0).choice(n, 512, replace=False))
+    sub_rp = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.cumsum(rp[rows + 1] - rp[rows], out=sub_rp[1:])
+    idx = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in rows])
+    y64, bound = c_oracle.spmm_csr_f64acc(sub_rp, c[idx], v[idx], x.cpu().numpy(), want_bound=True)
+    assert_fwd_close(y.cpu().numpy()[rows], y64, bound, what="reddit-shaped sample")
+
+
 @pytest.mark.parametrize("F", [64, 128, 602])
 @pytest.mark.parametrize("reduce", ["sum", "mean"])
 @pytest.mark.parametrize("mode", [1, 2, 3])
