@@ -88,3 +88,42 @@ def test_against_module_loop_random():
     l64 = orc.pge_edge_logits(params, emb, np.float64).reshape(len(rows), n)
     lg = m.score_all_pairs(Z, logits=True)[rows].cpu().numpy()
     assert np.allclose(lg, l64, rtol=2e-5, atol=2e-5)
+
+
+def test_full_size_c4_properties():
+    """BASELINE config 4 at full size (n = 25 000 condensed nodes, d = 128 with aggr -> nfeat 256, H = 256):
+    three rows of the 6.25e8-pair score matrix against the reference-style module call and the float64
+    oracle, and the structural properties of the edge list (symmetric, unit diagonal, torch.nonzero order)."""
+    from disco_amd.models.parametrized_adj_lp import PGE_Edge
+    torch.manual_seed(5)
+    n, nfeat = 25000, 256
+    m = PGE_Edge(nfeat=nfeat).to(DEV).eval()
+    with torch.no_grad():
+        for bn in m.bns:
+            bn.running_mean.normal_(0, 0.3)
+            bn.running_var.uniform_(0.3, 1.7)
+    Z = torch.randn(n, nfeat, device=DEV) * 0.5
+    S = m.score_all_pairs(Z)
+    rows = [0, 12345, n - 1]
+    for i in rows:
+        ref = m.inference(torch.cat([Z[[i] * n], Z], axis=1)).detach()      # LargeScaleCondensing.py:305
+        assert torch.allclose(S[i], ref, rtol=0, atol=3e-6)
+    params = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    Zc = Z.cpu().numpy()
+    cols = np.arange(0, n, 97)
+    emb = np.concatenate([np.repeat(Zc[rows], len(cols), axis=0), np.tile(Zc[cols], (len(rows), 1))], axis=1)
+    p64 = orc.sigmoid(orc.pge_edge_logits(params, emb, np.float64)).reshape(len(rows), len(cols))
+    assert np.allclose(S[rows][:, cols].cpu().numpy(), p64, rtol=0, atol=2e-6)
+    thr = float(torch.quantile(S[:2000, :2000].flatten(), 0.999))          # keep ~0.1 % of the pairs
+    ei, ew = m.edges_from_scores(S, thr, "transductive")
+    E = ei.shape[1]
+    assert n <= E < n * n // 100
+    key = ei[0] * n + ei[1]
+    assert bool((key[1:] > key[:-1]).all())                                # row-major, strictly increasing
+    tkey, order = torch.sort(ei[1] * n + ei[0])
+    assert torch.equal(tkey, key) and torch.equal(ew[order], ew)           # symmetric pattern and weights
+    diag = ei[0] == ei[1]
+    assert int(diag.sum()) == n and bool((ew[diag] == 1).all())
+    off = ~diag
+    a = (S[ei[0][off], ei[1][off]] + S[ei[1][off], ei[0][off]]) / 2.0
+    assert torch.equal(ew[off], a) and bool((a >= thr).all())
