@@ -274,6 +274,8 @@ def normalize_adj_partition(rowptr: torch.Tensor, col: torch.Tensor, val: Option
         flag[0] = int(bool(((row == 0) & (col == 0) & (val != 0)).any()))
     if world > 1:
         owner = next(g for g in range(world) if col_offsets[g + 1] > 0)
+        if dist.get_backend(group) != "gloo":
+            flag = flag.to(dev)                  # RCCL moves device tensors only
         dist.broadcast(flag, src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
     add_identity = 0 if int(flag[0]) else 1
     if add_identity:
