@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ r
 // block per window.  Windows are visited in ascending column order, i.e. each row still sums its entries
 // in CSR order: the only difference to k_spmm_rows is that the running sum passes through memory (no
 // rounding: float32 in, float32 out) -- same bits.
-template <int VEC, int G, int NV, bool HASVAL, bool A24>
+template <int VEC, int G, int NV, int OP, bool HASVAL, bool A24>
 __global__ __launch_bounds__(256, NV == 1 ? 6 : 1) void k_spmm_rows_win(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                        const float* __restrict__ val, const float* __restrict__ x,
                                                        int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256, NV == 1 ? 6 : 1) void k_spmm_rows_win(const in
   int64_t off[NV];
   lane_offsets<VEC, G, NV>(nvec, gl, off);
   const bool resume = !first_window || (flags & FLAG_ACCUM);
-  const bool finalize = last_window && (flags & FLAG_MEAN);
+  // last window: the mean divides by the row length, the maximum of an empty row becomes 0
+  const bool finalize = last_window && (OP == OP_MAX || (flags & FLAG_MEAN));
   uint32_t mb[MAXR], me[MAXR], mrow[MAXR];
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256, NV == 1 ? 6 : 1) void k_spmm_rows_win(const in
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int idx = gl + G * v;
-      yv[v] = 0.0f;
+      vinit<VEC, OP>(yv[v]);
       if (resume && idx < nvec) yv[v] = *reinterpret_cast<const V*>(yr + (int64_t)idx * VEC);
     }
   };
@@ -318,10 +319,14 @@ __global__ __launch_bounds__(256, NV == 1 ? 6 : 1) void k_spmm_rows_win(const in
       // nothing to add and nothing to finalise: leave the row alone
       if (end != beg || first_window || finalize) {
         const int n0 = end - beg < G ? (int)(end - beg) : G;
-        consume_batch<VEC, G, NV, OP_SUM, HASVAL, A24>(cv, wv, n0, x, ldx, off, acc);
-        if (end - beg > G) accumulate_range<VEC, G, NV, OP_SUM, HASVAL, A24>(beg + G, end, col, val, x, ldx, nvec, gl, acc);
+        consume_batch<VEC, G, NV, OP, HASVAL, A24>(cv, wv, n0, x, ldx, off, acc);
+        if (end - beg > G) accumulate_range<VEC, G, NV, OP, HASVAL, A24>(beg + G, end, col, val, x, ldx, nvec, gl, acc);
         float cnt = 0.0f;
-        if (finalize) cnt = (float)(rowptr[row + 1] - rowptr[row]);
+        bool empty_row = false;
+        if (finalize) {
+          const int64_t rn = rowptr[row + 1] - rowptr[row];
+          if constexpr (OP == OP_MAX) empty_row = rn == 0; else cnt = (float)rn;
+        }
         float* yr = y + row * ldy;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -329,6 +334,7 @@ __global__ __launch_bounds__(256, NV == 1 ? 6 : 1) void k_spmm_rows_win(const in
           if (idx < nvec) {
             V a = acc[v];
             if (cnt > 0.0f) a = vdiv<VEC>(a, cnt);
+            if (empty_row) a = 0.0f;
             *reinterpret_cast<V*>(yr + (int64_t)idx * VEC) = a;
           }
         }
@@ -743,7 +749,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       }
     }
   }
-  if constexpr (OP == OP_SUM && (VEC == 4 || VEC == 2)) {
+  if constexpr (VEC == 4 || VEC == 2) {
     // windowed launches (L2-blocked): mean of an accumulating call is not meaningful, so SUM_ACC + MEAN never meet
     if (!swept && count > 0 && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && tuning().sweep_mode >= 2) {
       const disco_schedule_info& s = *a.info;
@@ -754,7 +760,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       int64_t blocks = (count + 4 * RPW * rpg - 1) / (4 * RPW * rpg);
       if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
       for (int w = 0; w < P; ++w) {
-        hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, HASVAL, A24>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
+        hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, OP, HASVAL, A24>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
                            a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, wptr + (int64_t)w * s.sweep_count_padded,
                            wptr + (int64_t)(w + 1) * s.sweep_count_padded, w == 0, w == P - 1, mean, rpg);
       }
@@ -856,7 +862,7 @@ int spmm_dispatch(const SpmmArgs& a0) {
   int64_t max_cols = (int64_t)5 * 64 * vec;
   a.addr24 = tuning().addr24 && a.info && a.info->n_cols > 0 && a.info->n_cols <= (1 << 24) && a.ldx * 4 < (1 << 24) &&
              a.info->n_cols * a.ldx * 4 <= 0xffffffffLL;
-  if (vec >= 2 && a.reduce != DISCO_REDUCE_MAX && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && tuning().sweep_mode) {
+  if (vec >= 2 && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && tuning().sweep_mode) {
     // L2-blocked modes work on balanced column blocks (multiples of 32 floats): <= 256 floats for the
     // persistent sweep kernel (one float4 per lane), `win_cols` (default 128) for the windowed launches
     const int64_t cap = tuning().sweep_mode == 1 ? 256 : (tuning().win_cols > 0 ? tuning().win_cols : 128);

@@ -61,7 +61,7 @@ def spmm_raw(adj: SparseTensor, x: torch.Tensor, reduce: str = "sum", out: Optio
         stream = _lib.current_stream(x.device)
         ws_ptr, info_ref, sws, sws_bytes = None, None, None, 0
         if use_schedule and n > 0:
-            ws, info = adj.schedule(feat=F if reduce != "max" else None)
+            ws, info = adj.schedule(feat=F)
             ws_ptr, info_ref = _lib.ptr(ws), info
             need = lib.disco_spmm_workspace_bytes(info, F)
             if need:

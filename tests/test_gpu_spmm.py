@@ -254,7 +254,7 @@ def test_full_size_properties_reddit_shaped():
 
 
 @pytest.mark.parametrize("F", [64, 128, 602])
-@pytest.mark.parametrize("reduce", ["sum", "mean"])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
 @pytest.mark.parametrize("mode", [1, 2, 3])
 def test_sweep_kernel_same_bits_as_plain(F, reduce, mode):
     """The L2-blocked variants (1 = persistent sweep kernel, 2 = windowed launches) visit each row's entries
@@ -281,6 +281,11 @@ def test_sweep_kernel_same_bits_as_plain(F, reduce, mode):
     keep = np.ones(n, dtype=bool)
     keep[[0, 7]] = False
     assert np.array_equal(y_plain[keep], y_sweep[keep])
+    if reduce == "max":          # order independent: every row, and the oracle, bit for bit (modes 1/3 fall back to windows)
+        assert np.array_equal(y_plain, y_sweep)
+        assert np.array_equal(y_sweep, c_oracle.spmm_csr_f32(rowptr, col, val, x, "max"))
+        _lib.load().disco_set_tuning(b"sweep_mode", 2)
+        return
     y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x, want_bound=True)
     if reduce == "mean":
         cnt = np.maximum(np.diff(rowptr), 1)[:, None].astype(np.float64)
