@@ -86,7 +86,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
-    from disco_amd import SparseTensor, _lib, graphgen, ops, utils
+    from disco_amd import SparseTensor, _lib, graphgen, utils
     lib = _lib.load()
 
     name = args.workload

@@ -6,7 +6,7 @@ section 2 row 3); data loading, metrics and the nettack helpers are out of scope
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple, Union
+from typing import Optional, Union
 
 import torch
 
