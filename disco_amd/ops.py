@@ -25,6 +25,13 @@ def _as_operand(x: torch.Tensor) -> torch.Tensor:
         raise ValueError("features must be [N, F]")
     if x.stride(1) != 1 or x.stride(0) < x.shape[1]:
         x = x.contiguous()
+    if x.shape[1] >= 4 and (x.stride(0) % 4 or x.data_ptr() % 16) and x.shape[0] > 0:
+        # rows that are not 16-byte aligned (e.g. the [N, 41] output of GCNConv's last `lin`,
+        # /root/reference/models/convs_large/gcn_conv.py:157) would be gathered with scalar loads: one copy
+        # of N*F floats into a padded buffer buys 128-bit gathers for all nnz*F of them
+        buf = _padded_empty(x.shape[0], x.shape[1], x.device)
+        buf.copy_(x)
+        x = buf
     return x
 
 
