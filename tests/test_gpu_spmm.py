@@ -304,3 +304,23 @@ def test_sweep_refuses_unsorted_columns():
     y = ops.spmm_raw(adj, torch.from_numpy(x).to(dev()), "sum").cpu().numpy()
     y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x, want_bound=True)
     assert_fwd_close(y, y64, bound)
+
+
+@pytest.mark.parametrize("sweep", [False, True])
+def test_sum_acc_accumulates_onto_existing_output(sweep):
+    """DISCO_REDUCE_SUM_ACC (y += A x, the halo step of the row partition), plain and windowed: the running sum
+    starts from the value already in y, so the result is fl(y0 + sum) with the sum continued in CSR order."""
+    from disco_amd import ops
+    n, F = 4000, 128
+    rowptr, col, val = random_csr(n, n, 70, seed=41, hubs=[(3, 9000)], weighted=True)
+    x = np.random.default_rng(9).standard_normal((n, F)).astype(np.float32)
+    y0 = np.random.default_rng(10).standard_normal((n, F)).astype(np.float32)
+    adj = to_adj(rowptr, col, val, n)
+    ws, info = adj.schedule(feat=F, sweep=sweep)
+    assert bool(info.sweep_ws) == sweep
+    out = torch.from_numpy(y0.copy()).to(dev())
+    ops.spmm_raw(adj, torch.from_numpy(x).to(dev()), "sum_acc", out=out)
+    y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x, want_bound=True)
+    assert_fwd_close(out.cpu().numpy(), y64 + y0.astype(np.float64), bound + np.abs(y0), what=f"sum_acc sweep={sweep}")
+    empty = np.diff(rowptr) == 0
+    assert empty.any() and np.array_equal(out.cpu().numpy()[empty], y0[empty])      # rows without entries keep y0
