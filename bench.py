@@ -51,13 +51,11 @@ def parse():
 
 
 def auto_slices(n_rows_x: int, F: int) -> int:
-    """Column slices so that one slice of X (the gathered table) stays under ~190 MB, i.e. resident in
-    the 256 MiB Infinity Cache next to the streamed CSR and Y."""
-    budget = 190e6
-    s = 1
-    while n_rows_x * ((F + s - 1) // s) * 4 > budget and (F + s - 1) // s > 32:
-        s += 1
-    return s
+    """Column slices per hop.  Slicing X so that one slice fits the 256 MiB Infinity Cache does not pay: a gather
+    that misses L2 costs the same whether MALL or HBM serves it, while every slice re-reads
+    (col, val) and narrows the lane groups -- products 8.4 -> 7.0 ms, papers100M shard 36.6 -> 26.7 ms per step
+    with one slice (profiles/r1/other_workloads.log)."""
+    return 1
 
 
 def b_min_bytes(nnz: int, n_rows: int, n_x_rows: int, F: int) -> float:
