@@ -48,3 +48,24 @@ def test_argument_validation_without_gpu():
     assert lib.disco_spmm_csr_f32(None, None, None, 5, None, 4, None, 4, 4, 0, None, None, None, 0, None) == -1
     assert lib.disco_khop_csr_f32(None, None, None, 5, 0, None, 4, None, 4, None, None, 4, 4, 1, None, None, None, 0, None) == -1
     assert lib.disco_set_tuning(b"nope", 1) == -1
+
+
+def test_argument_validation_of_the_set_up_entry_points():
+    import ctypes as C
+    from disco_amd import _lib
+    lib = _lib.load()
+    nnz = C.c_int64(7)
+    # negative sizes, missing outputs, unknown duplicate mode, symmetrise on a rectangular shape
+    assert lib.disco_coo_to_csr(None, None, None, -1, 4, 4, 0, None, None, None, C.byref(nnz), None, 0, None) == -1
+    assert lib.disco_coo_to_csr(None, None, None, 3, 4, 4, 0, None, None, None, None, None, 0, None) == -1
+    assert lib.disco_coo_to_csr(None, None, None, 3, 4, 4, 6, 1, None, None, C.byref(nnz), None, 0, None) == -1
+    assert lib.disco_coo_to_csr(None, None, None, 3, 4, 5, 1, 1, None, None, C.byref(nnz), None, 0, None) == -1
+    assert lib.disco_coo_to_csr(None, None, None, 3, 4, 2 ** 31, 0, 1, None, None, C.byref(nnz), None, 0, None) == -2
+    assert lib.disco_coo_to_csr_workspace_bytes(-1, 0, 0) == 0
+    # pair gather: row pitch smaller than the width, output pitch smaller than two halves, empty work
+    assert lib.disco_pair_gather_f32(None, 10, 4, 8, None, None, None, 5, 5, None, 16, None, None) == -1
+    assert lib.disco_pair_gather_f32(None, 10, 8, 8, None, None, None, 5, 5, None, 15, None, None) == -1
+    assert lib.disco_pair_gather_f32(None, 10, 8, 8, None, None, None, 5, 0, None, 16, None, None) == 0
+    assert lib.disco_pair_gather_f32(None, 10, 8, 8, None, None, None, 5, 5, None, 16, None, None) == -1
+    # scorer: unsupported hidden width
+    assert lib.disco_pairscore_workspace_bytes(-1, 256) == 0
