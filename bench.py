@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--skew", type=float, default=None)
     ap.add_argument("--sweep", default="auto", choices=["auto", "on", "off"],
                     help="L2-blocked windowed launches (auto: when the graph re-uses source rows enough)")
+    ap.add_argument("--halo-frac", type=float, default=0.25,
+                    help="N > 1: share of every rank's entries whose column belongs to another rank (reported in config)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; reported in config)")
     return ap.parse_args()
 
@@ -153,7 +155,7 @@ def main():
         halo_info = None
     else:
         from disco_amd import dist as ddist
-        part = ddist.build_weak_scaling_partition(spec, n_local, nnz_target, skew, world, rank, dev, ld)
+        part = ddist.build_weak_scaling_partition(spec, n_local, nnz_target, skew, world, rank, dev, ld, halo_frac=args.halo_frac)
         nnz = part.nnz_local
         n_slices = 1
         events = []
