@@ -21,7 +21,7 @@ from . import _lib
 
 
 WIN_COLS = 128           # column block width of the windowed launches (libdisco_hip default)
-WINDOW_BYTES = 6 << 20   # measured optimum on MI355X (4 MiB L2 per XCD): fewer, slightly over-sized windows win
+WINDOW_BYTES = 5632 << 10   # 5.5 MiB: flat optimum 5-6 MiB on Reddit (profiles/r1/tune_window_fine.log)
 
 
 WIN_HUB_THRESHOLD, WIN_HUB_PIECE = 8192, 4096   # hub split used with windowed launches (tune_hub_windowed.log)
