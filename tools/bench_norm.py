@@ -3,19 +3,18 @@
   * A1  utils.gcn_norm(edge_index [2,E] int64, None, N, add_self_loops=False)  (_Sampled.py:491 call shape)
         algorithmic bytes: E*8 (col, degree) + E*16 (row, col) + E*4 (out) + N*12
   * A3  disco_csr_rowsum_f64 + disco_gcn_norm_csr_f32 on a built CSR: nnz*12 + N*16
-HIP-event timing, median of reps; CPU: the oracle's restatements on a bounded sample."""
+HIP-event timing, median of reps.  (The CPU side of these kernels is timed in bench.py / the tests only: tools do
+not touch oracle/.)"""
 import argparse
 import json
 import os
 import sys
-import time
 
 import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 from disco_amd import SparseTensor, _lib, graphgen, utils  # noqa: E402
 
@@ -37,7 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="products")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--cpu-edges", type=int, default=3_000_000)
+    ap.add_argument("--cpu-edges", type=int, default=0, help="unused (kept for old command lines)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     spec = graphgen.SPECS[args.workload]
@@ -63,14 +62,6 @@ def main():
     ms, _ = timed(csr_kernels, args.reps)
     b = adj.nnz() * 12 + n * 16
     out["normalize_adj_csr_kernels"] = {"ms": ms, "algorithmic_GB": b / 1e9, "GBs": b / ms / 1e6, "frac_of_8TBs": b / ms / 1e6 / 8000}
-    # host: oracle restatement of A1 on a bounded sample
-    import disco_oracle as orc
-    k = min(args.cpu_edges, E)
-    sub = ei[:, :k].cpu().numpy()
-    t0 = time.perf_counter()
-    orc.gcn_norm_coo(sub, None, n, add_self_loops=False)
-    cpu = time.perf_counter() - t0
-    out["cpu_oracle_gcn_norm"] = {"edges": k, "seconds": cpu, "edges_per_s": k / cpu, "gpu_edges_per_s": E / out["gcn_norm_coo"]["ms"] * 1e3}
     print(json.dumps(out))
 
 
