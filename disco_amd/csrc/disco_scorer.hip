@@ -45,29 +45,67 @@ static ScorerWs scorer_layout(int64_t n, int64_t H) {
 }
 
 // ---- prepare: U, V (float32 dot products in k order), folded W2', b2', w3, b3 ----------------------
-// one thread per (node, hidden unit); D is small (<= a few hundred): Z row and W1 row are L1/L2 hits.
+// A workgroup computes a 64-node x 64-unit tile of U and V; Z and the two halves of W1 are staged through LDS
+// in chunks of 16 k-values, each thread owns 4 nodes x 4 units.  Every output is one fmaf chain over
+// k = 0 .. D-1 in ascending order (what a plain dot-product loop gives), whatever the tiling.
+constexpr int kUvTile = 64, kUvK = 16;
 __global__ __launch_bounds__(256) void k_scorer_uv(const float* __restrict__ Z, int64_t n, int64_t D, int64_t ldz,
                                                    const float* __restrict__ W1, const float* __restrict__ b1,
                                                    const float* __restrict__ g1, const float* __restrict__ be1,
                                                    const float* __restrict__ m1, const float* __restrict__ v1, float eps,
                                                    int H, float* __restrict__ U, float* __restrict__ V) {
-  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n * H) return;
-  const int64_t i = idx / H;
-  const int h = (int)(idx % H);
-  const float* z = Z + i * ldz;
-  const float* wa = W1 + (int64_t)h * 2 * D;
-  const float* wb = wa + D;
-  float su = 0.0f, sv = 0.0f;
-  for (int64_t k = 0; k < D; ++k) {
-    const float zk = z[k];
-    su = fmaf(zk, wa[k], su);
-    sv = fmaf(zk, wb[k], sv);
+  __shared__ float zt[kUvTile][kUvK + 1], wa[kUvTile][kUvK + 1], wb[kUvTile][kUvK + 1];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const int64_t i0 = (int64_t)blockIdx.x * kUvTile;
+  const int h0 = blockIdx.y * kUvTile;
+  float su[4][4], sv[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { su[a][b] = 0.0f; sv[a][b] = 0.0f; }
+  for (int64_t k0 = 0; k0 < D; k0 += kUvK) {
+    // stage: 64 x 16 elements of each operand, 4 per thread (k fastest: coalesced 64-byte rows)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = t + 256 * q, r = e >> 4, k = e & 15;
+      const int64_t kk = k0 + k;
+      const int64_t i = i0 + r;
+      const int h = h0 + r;
+      zt[r][k] = (i < n && kk < D) ? Z[i * ldz + kk] : 0.0f;
+      wa[r][k] = (h < H && kk < D) ? W1[(int64_t)h * 2 * D + kk] : 0.0f;
+      wb[r][k] = (h < H && kk < D) ? W1[(int64_t)h * 2 * D + D + kk] : 0.0f;
+    }
+    __syncthreads();
+    const int kmax = D - k0 < kUvK ? (int)(D - k0) : kUvK;     // padding must not extend the fmaf chain
+    for (int k = 0; k < kmax; ++k) {
+      float zr[4], ar[4], br[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) zr[a] = zt[ty * 4 + a][k];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { ar[b] = wa[tx * 4 + b][k]; br[b] = wb[tx * 4 + b][k]; }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { su[a][b] = fmaf(zr[a], ar[b], su[a][b]); sv[a][b] = fmaf(zr[a], br[b], sv[a][b]); }
+    }
+    __syncthreads();
   }
-  const float s = g1[h] / sqrtf(v1[h] + eps);
-  const float t = be1[h] - m1[h] * s;
-  U[idx] = s * su;
-  V[idx] = s * (sv + b1[h]) + t;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int h = h0 + tx * 4 + b;
+    if (h >= H) continue;
+    const float s = g1[h] / sqrtf(v1[h] + eps);
+    const float tt = be1[h] - m1[h] * s;
+    const float bb = b1[h];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int64_t i = i0 + ty * 4 + a;
+      if (i < n) {
+        U[i * H + h] = s * su[a][b];
+        V[i * H + h] = s * (sv[a][b] + bb) + tt;
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_scorer_fold(const float* __restrict__ W2, const float* __restrict__ b2,
@@ -381,7 +419,7 @@ extern "C" int disco_pairscore_prepare_f32(const float* Z, int64_t n, int64_t D,
   hipStream_t s = static_cast<hipStream_t>(stream_);
   char* w = static_cast<char*>(ws);
   if (n > 0) {
-    hipLaunchKernelGGL(k_scorer_uv, dim3((unsigned)((n * H + 255) / 256)), dim3(256), 0, s, Z, n, D, ldz, W1, b1, bn1_w, bn1_b,
+    hipLaunchKernelGGL(k_scorer_uv, dim3((unsigned)((n + kUvTile - 1) / kUvTile), (unsigned)((H + kUvTile - 1) / kUvTile)), dim3(256), 0, s, Z, n, D, ldz, W1, b1, bn1_w, bn1_b,
                        bn1_mean, bn1_var, eps, (int)H, reinterpret_cast<float*>(w + L.off_u), reinterpret_cast<float*>(w + L.off_v));
   }
   hipLaunchKernelGGL(k_scorer_fold, dim3((unsigned)((H * H + 255) / 256)), dim3(256), 0, s, W2, b2, bn2_w, bn2_b, bn2_mean, bn2_var,
