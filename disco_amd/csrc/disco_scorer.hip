@@ -300,98 +300,51 @@ __global__ __launch_bounds__(512) void k_scorer_pairs(const float* __restrict__ 
 // variant 1 inductive   : A = (S + S^T)/2; diag = 1; A[A < thr] = 0        (LargeScaleCondensing_induct.py:300-302)
 // variant 2 sampled     : off-diagonal as above (both directions averaged, thresholded, symmetric);
 //                         the n unit self-loops are APPENDED after the sorted edge list (_Sampled.py:271-285)
-// Both passes walk the matrix in 64 x 64 tiles: a workgroup owns a strip of 64 rows; for every column tile it
-// stages the TRANSPOSED block S[j0.., i0..] in LDS with coalesced reads (reading S[j][i] straight from memory
-// touches one 128-byte line per element: 80 GB of line traffic at n = 25 000), then each of its four waves
-// handles 16 rows, lane b = column j0 + b.  Columns are visited in ascending order, so the compaction by
-// ballot / popcount yields torch.nonzero order.
-constexpr int kSymTile = 64;
-
-__device__ __forceinline__ void sym_stage_transposed(const float* __restrict__ S, int64_t n, int64_t lds, int64_t i0, int64_t j0,
-                                                     float (&tileT)[kSymTile][kSymTile + 1]) {
-  // tileT[b][a] = S[j0 + b][i0 + a]
-  const int a = threadIdx.x & 63;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int b = (threadIdx.x >> 6) + 4 * k;
-    const int64_t i = i0 + a, j = j0 + b;
-    tileT[b][a] = (i < n && j < n) ? S[j * lds + i] : 0.0f;
-  }
-}
-
-__device__ __forceinline__ float sym_value_t(float sij, float sji, int64_t i, int64_t j, float thr, int variant) {
+__device__ __forceinline__ float sym_value(const float* __restrict__ S, int64_t lds, int64_t i, int64_t j, float thr,
+                                           int variant) {
   if (i == j) {
     if (variant == 2) return 0.0f;
     if (variant == 1) return 1.0f < thr ? 0.0f : 1.0f;
     return 1.0f;
   }
-  const float a = (sij + sji) / 2.0f;
+  const float a = (S[i * lds + j] + S[j * lds + i]) / 2.0f;
   return a < thr ? 0.0f : a;
 }
 
 __global__ __launch_bounds__(256) void k_sym_count(const float* __restrict__ S, int64_t n, int64_t lds, float thr, int variant,
                                                    int64_t* __restrict__ rowcount) {
-  __shared__ float tileT[kSymTile][kSymTile + 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t i0 = (int64_t)blockIdx.x * kSymTile;
-  int cnt[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) cnt[q] = 0;
-  for (int64_t j0 = 0; j0 < n; j0 += kSymTile) {
+  const int64_t i = blockIdx.x;
+  int cnt = 0;
+  for (int64_t j = threadIdx.x; j < n; j += 256) cnt += sym_value(S, lds, i, j, thr, variant) != 0.0f;
+  __shared__ int part[256];
+  part[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
     __syncthreads();
-    sym_stage_transposed(S, n, lds, i0, j0, tileT);
-    __syncthreads();
-    const int64_t j = j0 + lane;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int a = wave * 16 + q;
-      const int64_t i = i0 + a;
-      float v = 0.0f;
-      if (i < n && j < n) v = sym_value_t(S[i * lds + j], tileT[lane][a], i, j, thr, variant);
-      cnt[q] += __popcll(__ballot(v != 0.0f));
-    }
   }
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int64_t i = i0 + wave * 16 + q;
-      if (i < n) rowcount[i] = cnt[q];
-    }
-  }
+  if (threadIdx.x == 0) rowcount[i] = part[0];
 }
 
-__global__ __launch_bounds__(256) void k_sym_fill(const float* __restrict__ S, int64_t n, int64_t lds, float thr, int variant,
-                                                  const int64_t* __restrict__ rowstart, int64_t E, int64_t* __restrict__ ei,
-                                                  float* __restrict__ ew) {
-  __shared__ float tileT[kSymTile][kSymTile + 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t i0 = (int64_t)blockIdx.x * kSymTile;
-  int64_t pos[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int64_t i = i0 + wave * 16 + q;
-    pos[q] = i < n ? rowstart[i] : 0;
-  }
-  for (int64_t j0 = 0; j0 < n; j0 += kSymTile) {
-    __syncthreads();
-    sym_stage_transposed(S, n, lds, i0, j0, tileT);
-    __syncthreads();
-    const int64_t j = j0 + lane;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int a = wave * 16 + q;
-      const int64_t i = i0 + a;
-      float v = 0.0f;
-      if (i < n && j < n) v = sym_value_t(S[i * lds + j], tileT[lane][a], i, j, thr, variant);
-      const unsigned long long m = __ballot(v != 0.0f);
-      if (v != 0.0f) {
-        const int64_t p = pos[q] + __popcll(m & ((1ull << lane) - 1ull));
-        ei[p] = i;
-        ei[E + p] = j;
-        ew[p] = v;
-      }
-      pos[q] += __popcll(m);
+// one 64-lane wave per row keeps the columns in ascending order (torch.nonzero order)
+__global__ __launch_bounds__(64) void k_sym_fill(const float* __restrict__ S, int64_t n, int64_t lds, float thr, int variant,
+                                                 const int64_t* __restrict__ rowstart, int64_t E, int64_t* __restrict__ ei,
+                                                 float* __restrict__ ew) {
+  const int64_t i = blockIdx.x;
+  int64_t pos = rowstart[i];
+  const int lane = threadIdx.x;
+  for (int64_t jb = 0; jb < n; jb += 64) {
+    const int64_t j = jb + lane;
+    float a = 0.0f;
+    if (j < n) a = sym_value(S, lds, i, j, thr, variant);
+    const unsigned long long m = __ballot(a != 0.0f);
+    if (a != 0.0f) {
+      const int64_t p = pos + __popcll(m & ((1ull << lane) - 1ull));
+      ei[p] = i;
+      ei[E + p] = j;
+      ew[p] = a;
     }
+    pos += __popcll(m);
   }
 }
 
@@ -470,7 +423,7 @@ extern "C" int disco_sym_threshold_count(const float* S, int64_t n, int64_t lds,
   if (n < 0 || variant < 0 || variant > 2) return DISCO_EINVAL;
   if (n == 0) return DISCO_OK;
   if (!S || !rowcount || lds < n) return DISCO_EINVAL;
-  hipLaunchKernelGGL(k_sym_count, dim3((unsigned)((n + kSymTile - 1) / kSymTile)), dim3(256), 0, static_cast<hipStream_t>(stream_), S, n, lds, threshold, variant,
+  hipLaunchKernelGGL(k_sym_count, dim3((unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream_), S, n, lds, threshold, variant,
                      rowcount);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
@@ -481,7 +434,7 @@ extern "C" int disco_sym_threshold_fill(const float* S, int64_t n, int64_t lds, 
   if (n < 0 || E < 0 || variant < 0 || variant > 2) return DISCO_EINVAL;
   if (n == 0 || E == 0) return DISCO_OK;
   if (!S || !rowstart || !edge_index || !edge_weight || lds < n) return DISCO_EINVAL;
-  hipLaunchKernelGGL(k_sym_fill, dim3((unsigned)((n + kSymTile - 1) / kSymTile)), dim3(256), 0, static_cast<hipStream_t>(stream_), S, n, lds, threshold, variant,
+  hipLaunchKernelGGL(k_sym_fill, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream_), S, n, lds, threshold, variant,
                      rowstart, E, edge_index, edge_weight);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
