@@ -324,3 +324,28 @@ def test_sum_acc_accumulates_onto_existing_output(sweep):
     assert_fwd_close(out.cpu().numpy(), y64 + y0.astype(np.float64), bound + np.abs(y0), what=f"sum_acc sweep={sweep}")
     empty = np.diff(rowptr) == 0
     assert empty.any() and np.array_equal(out.cpu().numpy()[empty], y0[empty])      # rows without entries keep y0
+
+
+@pytest.mark.parametrize("ld", [602, 601])
+def test_windowed_path_with_narrow_vectors(ld):
+    """ld = 602: rows are only 8-byte aligned -> 64-bit gathers, still windowed; ld = 601: scalar loads, the
+    window table is ignored and the plain kernel runs.  Both must meet the forward-error bar."""
+    from disco_amd import _lib, ops
+    lib = _lib.load()
+    n, F = 3000, min(ld, 602)
+    rowptr, col, val = random_csr(n, n, 50, seed=51, hubs=[(1, 2500)], weighted=True)
+    x = np.random.default_rng(3).standard_normal((n, F)).astype(np.float32)
+    buf = torch.zeros((n, ld), device=dev())
+    buf[:, :F] = torch.from_numpy(x).to(dev())
+    adj = to_adj(rowptr, col, val, n)
+    ws, info = adj.schedule(feat=F, sweep=True)
+    assert info.sweep_ws
+    sws = torch.empty(max(int(lib.disco_spmm_workspace_bytes(info, F)), 16), dtype=torch.uint8, device=dev())
+    out = torch.full((n, ld), 7.0, device=dev())
+    _lib.check(lib.disco_spmm_csr_f32(adj._rowptr.data_ptr(), adj._col32.data_ptr(), adj._value.data_ptr(), n,
+                                      buf.data_ptr(), ld, out.data_ptr(), ld, F, 0, ws.data_ptr(), info, sws.data_ptr(),
+                                      sws.numel(), _lib.current_stream(dev())), "spmm")
+    y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x, want_bound=True)
+    got = out.cpu().numpy()
+    assert_fwd_close(got[:, :F], y64, bound, what=f"ld={ld}")
+    assert np.all(got[:, F:] == 7.0)             # padding columns are never written
