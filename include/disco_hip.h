@@ -85,14 +85,16 @@ int disco_schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz,
                          int64_t hub_threshold, int64_t hub_piece, void* sched_ws,
                          size_t sched_ws_bytes, disco_schedule_info* info_host, void* stream);
 
-/* ---- L2-blocked sweep (optional, for graphs whose rows re-use source rows heavily) -----------
- * Builds the window pointers the sweep kernel needs (see disco_spmm.hip: source rows are cut into
- * windows of `window_rows` rows that fit the XCD's 4 MiB L2; all resident waves walk the windows
- * together with their row sums in registers).  Requires column indices sorted inside every row;
- * returns DISCO_EUNSUPPORTED (and leaves the schedule without a sweep) when they are not.
- * Once attached to `info_host`, disco_spmm_csr_f32 / disco_khop_csr_f32 use the sweep kernel for
- * sum / mean reductions on 16-byte aligned operands; results have the same bits as without it.
- * The caller keeps `sweep_ws` alive as long as `info_host` is used.  SYNCHRONISES `stream` once.
+/* ---- L2 window table (optional, for graphs whose rows re-use source rows heavily) ------------------
+ * Cuts the source rows (columns) into windows of `window_rows` rows sized for the XCD's 4 MiB L2 and records,
+ * per window and row of the schedule, where the row's entries of that window start (absolute uint32 offsets,
+ * hence nnz < 2^32).  Requires column indices sorted inside every row; returns DISCO_EUNSUPPORTED (and leaves
+ * the schedule without a table) when they are not.  Once attached to `info_host`, disco_spmm_csr_f32 /
+ * disco_khop_csr_f32 run 64/128-bit-aligned operands as one launch per (column block, window) -- all
+ * workgroups of a launch gather from the same few MB of x (Reddit: 1.9x).  Rows below the hub
+ * threshold get the same bits as without the table (sum, mean: same CSR order; max: order independent).
+ * The caller keeps `sweep_ws` alive as long as `info_host` is used (the kernels also use the last 1 MiB of it
+ * for pacing flags in the experimental sweep_mode 3).  SYNCHRONISES `stream` once.
  * No counterpart in the reference. */
 size_t disco_sweep_workspace_bytes(const disco_schedule_info* info_host, int64_t n_cols,
                                    int64_t window_rows);
@@ -123,9 +125,9 @@ int disco_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* v
  * y = A^K x for a square CSR A: `for k in range(K): x = propagate(adj_t, x=x)`
  * (/root/reference/models/convs_large/sg_conv.py:74-77).  tmp0/tmp1 are caller-owned
  * [n_rows, ldt] ping-pong buffers (tmp0 needed for K>=2, tmp1 for K>=3).
- * n_col_slices >= 1 runs the K hops independently on column slices of x (each slice's
- * working set then fits the 256 MiB Infinity Cache).  Rows below the hub threshold give the same
- * bits for any value; hub rows differ by rounding (their partial sums follow the lane-group width). */
+ * n_col_slices >= 1 runs the K hops independently on column slices of x (kept for callers that want
+ * a smaller working set; on MI355X one slice is fastest).  Rows below the hub threshold give
+ * the same bits for any value; hub rows differ by rounding (their partial sums follow the lane-group width). */
 int disco_khop_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n,
                        int K, const float* x, int64_t ldx, float* y, int64_t ldy, float* tmp0,
                        float* tmp1, int64_t ldt, int64_t F, int n_col_slices,
@@ -156,8 +158,8 @@ int disco_gcn_norm_csr_f32(const int64_t* rowptr, const int32_t* col, const floa
 
 /* gcn_norm, edge-index branch (/root/reference/utils.py:242-247; copy at
  * /root/reference/models/convs_large/gcn_conv.py:65-70).
- * Unweighted degree: deg[i] = #edges with idx == i, exact integers, then deg -> float32.
- * Replaces torch_scatter.scatter_add at utils.py:244 for edge_weight=None. */
+ * Unweighted degree: deg[i] = #edges with idx == i, exact integers, then deg -> float32; ids outside
+ * [0, N) are ignored.  Replaces torch_scatter.scatter_add at utils.py:244 for edge_weight=None. */
 int disco_degree_count_f32(const int64_t* idx, int64_t E, int64_t N, float* deg, void* stream);
 /* Weighted degree with the CPU reference's summation order: `order` is a stable argsort of
  * idx and `segptr` int64[N+1] its segment pointers; deg[i] = sequential float32 sum of
