@@ -61,6 +61,9 @@ _SIGNATURES = {
     "disco_coo_to_csr_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "disco_coo_to_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                  C.POINTER(c_int64), c_void_p, c_size_t, c_void_p]),
+    "disco_csr_insert_diagonal_workspace_bytes": (c_size_t, [c_int64]),
+    "disco_csr_insert_diagonal": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                          C.POINTER(c_int64), c_void_p, c_size_t, c_void_p]),
     "disco_pair_gather_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                       c_void_p, c_int64, c_void_p, c_void_p]),
 }

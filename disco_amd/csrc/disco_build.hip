@@ -223,3 +223,110 @@ extern "C" int disco_coo_to_csr(const int64_t* row, const int64_t* col, const fl
   *nnz_out = dup == DISCO_COO_DUP_KEEP ? L.m : h.nnz;
   return DISCO_OK;
 }
+
+// ---- structure of mx + I without a second sort -----------------------------------------------------------
+// normalize_adj adds the identity when node 0 has no self-loop (/root/reference/utils.py:425-426): every row
+// needs a diagonal entry.  On a CSR with sorted columns that is a merge, not a sort: one binary search per row
+// finds where the diagonal belongs and whether it is missing, an exclusive scan turns "missing" into the shift
+// of every row, and an entry-parallel copy moves each entry to its new place (a zero-valued diagonal entry is
+// written into the gap; the kernels of disco_norm.hip add the 1 in float64).
+namespace disco {
+
+__global__ void k_diag_probe(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n,
+                             int64_t* __restrict__ missing, int64_t* __restrict__ dpos) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  if (r == n) { missing[r] = 0; dpos[r] = rowptr[n]; return; }
+  int64_t lo = rowptr[r], hi = rowptr[r + 1];
+  const int64_t e = hi;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)col[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  dpos[r] = lo;
+  missing[r] = (lo < e && (int64_t)col[lo] == r) ? 0 : 1;
+}
+
+constexpr int kInsChunk = 2048;
+__global__ __launch_bounds__(256) void k_diag_insert(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                     const float* __restrict__ val, int64_t n, int64_t nnz,
+                                                     const int64_t* __restrict__ missing, const int64_t* __restrict__ shift,
+                                                     const int64_t* __restrict__ dpos, int64_t* __restrict__ rowptr_out,
+                                                     int32_t* __restrict__ col_out, float* __restrict__ val_out) {
+  // rows: new row pointers and the inserted diagonal entries (grid-stride over rows)
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= n; r += (int64_t)gridDim.x * 256) {
+    rowptr_out[r] = rowptr[r] + shift[r];
+    if (r < n && missing[r]) {
+      const int64_t p = dpos[r] + shift[r];
+      col_out[p] = (int32_t)r;
+      val_out[p] = 0.0f;
+    }
+  }
+  // entries: this workgroup's chunk, rows found by binary search inside the chunk's row range
+  const int64_t c0 = (int64_t)blockIdx.x * kInsChunk;
+  const int64_t c1 = c0 + kInsChunk < nnz ? c0 + kInsChunk : nnz;
+  if (c0 >= c1) return;
+  auto row_of = [&](int64_t lo, int64_t hi, int64_t i) {
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (rowptr[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+  };
+  const int64_t r_lo = row_of(0, n - 1, c0);
+  const int64_t r_hi = row_of(r_lo, n - 1, c1 - 1);
+  for (int64_t i = c0 + threadIdx.x; i < c1; i += 256) {
+    const int64_t r = row_of(r_lo, r_hi, i);
+    const int64_t p = i + shift[r] + ((missing[r] && i >= dpos[r]) ? 1 : 0);
+    col_out[p] = col[i];
+    val_out[p] = val ? val[i] : 1.0f;
+  }
+}
+
+}  // namespace disco
+
+extern "C" size_t disco_csr_insert_diagonal_workspace_bytes(int64_t n_rows) {
+  if (n_rows < 0) return 0;
+  size_t scan_tmp = 0;
+  if (rocprim::exclusive_scan(nullptr, scan_tmp, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(n_rows + 1),
+                              rocprim::plus<int64_t>()) != hipSuccess)
+    return 0;
+  return (size_t)(3 * align_up_b(8 * (n_rows + 1), 256)) + scan_tmp + 512;
+}
+
+extern "C" int disco_csr_insert_diagonal(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                                         int64_t nnz, int64_t* rowptr_out, int32_t* col_out, float* val_out,
+                                         int64_t* nnz_out, void* ws_, size_t ws_bytes, void* stream_) {
+  if (n_rows < 0 || nnz < 0 || !nnz_out) return DISCO_EINVAL;
+  if (n_rows > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
+  *nnz_out = 0;
+  if (n_rows == 0) return DISCO_OK;
+  if (!rowptr || !rowptr_out || !col_out || !val_out || !ws_ || (nnz > 0 && !col)) return DISCO_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int64_t slot = align_up_b(8 * (n_rows + 1), 256);
+  size_t scan_tmp = 0;
+  DISCO_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tmp, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0,
+                                        (size_t)(n_rows + 1), rocprim::plus<int64_t>()));
+  if ((size_t)(3 * slot) + scan_tmp + 512 > ws_bytes) return DISCO_EWORKSPACE;
+  char* ws = static_cast<char*>(ws_);
+  int64_t* missing = reinterpret_cast<int64_t*>(ws);
+  int64_t* shift = reinterpret_cast<int64_t*>(ws + slot);
+  int64_t* dpos = reinterpret_cast<int64_t*>(ws + 2 * slot);
+  void* tmp = ws + 3 * slot;
+  hipLaunchKernelGGL(k_diag_probe, dim3((unsigned)((n_rows + 256) / 256)), dim3(256), 0, stream, rowptr, col, n_rows, missing, dpos);
+  DISCO_CHECK_LAUNCH();
+  DISCO_HIP_TRY(rocprim::exclusive_scan(tmp, scan_tmp, (const int64_t*)missing, shift, (int64_t)0, (size_t)(n_rows + 1),
+                                        rocprim::plus<int64_t>(), stream));
+  int64_t blocks = (nnz + kInsChunk - 1) / kInsChunk;
+  const int64_t row_blocks = (n_rows + 256) / 256 < 4096 ? (n_rows + 256) / 256 : 4096;
+  if (blocks < row_blocks) blocks = row_blocks;
+  if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_diag_insert, dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, val, n_rows, nnz,
+                     (const int64_t*)missing, (const int64_t*)shift, (const int64_t*)dpos, rowptr_out, col_out, val_out);
+  DISCO_CHECK_LAUNCH();
+  int64_t added = 0;
+  DISCO_HIP_TRY(hipMemcpyAsync(&added, shift + n_rows, sizeof(added), hipMemcpyDeviceToHost, stream));
+  DISCO_HIP_TRY(hipStreamSynchronize(stream));
+  *nnz_out = nnz + added;
+  return DISCO_OK;
+}

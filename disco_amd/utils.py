@@ -135,6 +135,34 @@ def fill_diag(adj: SparseTensor, fill_value: float) -> SparseTensor:
                         value=torch.cat([val[keep], val.new_full((n,), fill_value)]), sparse_sizes=adj.sparse_sizes())
 
 
+def _with_diagonal(adj: SparseTensor, row: torch.Tensor, col: torch.Tensor, val: torch.Tensor) -> SparseTensor:
+    """CSR of the same matrix with a (zero-valued) diagonal entry in every row: the structure of ``mx + I``.
+    Columns sorted inside the rows (what every constructor of this package produces): a device merge,
+    ``disco_csr_insert_diagonal``; otherwise one more sort through ``coo_to_csr``."""
+    import ctypes
+    n, dev = adj.size(0), adj.device
+    lib = _lib.load()
+    # strictly increasing columns inside every row; duplicate entries take the sort path, which sums them
+    unsorted = bool(((col[1:] <= col[:-1]) & (row[1:] == row[:-1])).any()) if col.numel() > 1 else False
+    if adj.size(0) == adj.size(1) and not unsorted:
+        with torch.cuda.device(dev):
+            nb = lib.disco_csr_insert_diagonal_workspace_bytes(n)
+            ws = torch.empty(max(int(nb), 256), dtype=torch.uint8, device=dev)
+            rp = torch.empty(n + 1, dtype=torch.int64, device=dev)
+            c32 = torch.empty(adj.nnz() + n, dtype=torch.int32, device=dev)
+            v = torch.empty(adj.nnz() + n, dtype=torch.float32, device=dev)
+            nnz = ctypes.c_int64(0)
+            _lib.check(lib.disco_csr_insert_diagonal(_lib.ptr(adj._rowptr), _lib.ptr(adj._col32), _lib.ptr(val), n, adj.nnz(),
+                                                     _lib.ptr(rp), _lib.ptr(c32), _lib.ptr(v), ctypes.byref(nnz), _lib.ptr(ws),
+                                                     ws.numel(), _lib.current_stream(dev)), "disco_csr_insert_diagonal")
+        k = int(nnz.value)
+        return SparseTensor(rowptr=rp, col=c32[:k], value=v[:k], sparse_sizes=adj.sparse_sizes(), is_sorted=True)
+    d = torch.arange(n, device=dev)
+    rp, c32, v = coo_to_csr(torch.cat([row, d]), torch.cat([col, d]),
+                            torch.cat([val, torch.zeros(n, dtype=torch.float32, device=dev)]), adj.sparse_sizes(), dup="sum")
+    return SparseTensor(rowptr=rp, col=c32, value=v, sparse_sizes=adj.sparse_sizes(), is_sorted=True)
+
+
 def normalize_adj_csr(adj: SparseTensor) -> SparseTensor:
     """Core of ``normalize_adj`` (/root/reference/utils.py:406-435) on a CSR whose duplicates are
     already summed: ``if mx[0,0] == 0: mx += I``; r = rowsum^-1/2 (inf -> 0) in float64;
@@ -149,11 +177,7 @@ def normalize_adj_csr(adj: SparseTensor) -> SparseTensor:
     if add_identity:
         # Structure of mx + I: a zero-valued diagonal entry is merged into every row (x + 0 is exact in
         # float32); the kernels add the 1 in float64, as scipy's `mx + sp.eye(n)` does.
-        d = torch.arange(n, device=adj.device)
-        rp, c32, v = coo_to_csr(torch.cat([row, d]), torch.cat([col, d]),
-                                torch.cat([val.to(torch.float32), torch.zeros(n, dtype=torch.float32, device=adj.device)]),
-                                adj.sparse_sizes(), dup="sum")
-        adj = SparseTensor(rowptr=rp, col=c32, value=v, sparse_sizes=adj.sparse_sizes(), is_sorted=True)
+        adj = _with_diagonal(adj, row, col, val.to(torch.float32).contiguous())
     lib = _lib.load()
     with torch.cuda.device(adj.device):
         s = _lib.current_stream(adj.device)

@@ -238,6 +238,16 @@ int disco_coo_to_csr(const int64_t* row, const int64_t* col, const float* val, i
                      int64_t n_cols, int flags, int64_t* rowptr, int32_t* col_out, float* val_out, int64_t* nnz_out,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* Structure of `mx + I` (/root/reference/utils.py:425-426) on a CSR with sorted columns, without a second
+ * sort: rows that lack a diagonal entry get a ZERO-valued one at its sorted position (existing diagonal
+ * entries and all other entries are copied unchanged; disco_csr_rowsum_f64 / disco_gcn_norm_csr_f32 add the 1
+ * in float64).  rowptr_out[n_rows+1]; col_out / val_out need room for nnz + n_rows entries; *nnz_out (host)
+ * receives the new entry count.  val NULL = unit weights.  SYNCHRONISES the stream once.  Square matrices. */
+size_t disco_csr_insert_diagonal_workspace_bytes(int64_t n_rows);
+int disco_csr_insert_diagonal(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, int64_t nnz,
+                              int64_t* rowptr_out, int32_t* col_out, float* val_out, int64_t* nnz_out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---- Pair-embedding gather for the link predictor's training batches --------------------
  * out[p, :] = [ Z[src[e], 0:width] | Z[dst[e], 0:width] ],  e = sel ? sel[p] : p,  p < n_pairs.
  * Replaces `torch.concat((feat_transform[edge_index[0][index]], feat_transform[edge_index[1][index]]),

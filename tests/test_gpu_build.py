@@ -111,3 +111,31 @@ def test_end_to_end_raw_edges_to_normalised_adj_t():
     g, w = gval.cpu().numpy(), val.astype(np.float32)
     ulp = np.abs(g.view(np.int32).astype(np.int64) - w.view(np.int32).astype(np.int64))
     assert ulp.max() <= 1
+
+
+@pytest.mark.parametrize("n,avg", [(1, 0), (50, 3), (4000, 12), (90000, 6)])
+def test_diagonal_insertion_equals_the_sort_based_merge(n, avg):
+    """disco_csr_insert_diagonal (merge on sorted columns) against the same structure obtained by appending a
+    zero diagonal and sorting again: identical rowptr / col / val, incl. empty rows and rows that already hold
+    their diagonal entry."""
+    from disco_amd import SparseTensor
+    from disco_amd.sparse import coo_to_csr
+    from disco_amd.utils import _with_diagonal
+    rng = np.random.default_rng(n + avg)
+    e = n * avg
+    r = rng.integers(0, n, e)
+    c = rng.integers(0, n, e)
+    keep = rng.random(n) < 0.3                       # 30 % of the nodes get an explicit self-loop
+    r = np.concatenate([r, np.flatnonzero(keep)])
+    c = np.concatenate([c, np.flatnonzero(keep)])
+    key = np.unique(r * n + c)
+    r, c = key // n, key % n
+    v = rng.standard_normal(r.size).astype(np.float32)
+    adj = SparseTensor(row=torch.from_numpy(r).to(dev()), col=torch.from_numpy(c).to(dev()), value=torch.from_numpy(v).to(dev()),
+                       sparse_sizes=(n, n), is_sorted=True)
+    row, col, val = adj.coo()
+    got = _with_diagonal(adj, row, col, val)
+    d = torch.arange(n, device=dev())
+    rp, c32, vv = coo_to_csr(torch.cat([row, d]), torch.cat([col, d]), torch.cat([val, torch.zeros(n, device=dev())]), (n, n), dup="sum")
+    assert torch.equal(got._rowptr, rp) and torch.equal(got._col32, c32) and torch.equal(got._value, vv)
+    assert got.nnz() == r.size + n - int(np.unique(r[r == c]).size)
