@@ -5,6 +5,6 @@ Host side mirrors the reference's Python module API (``models.convs_large``, ``u
 behind the C ABI of ``include/disco_hip.h`` (``disco_amd/csrc/libdisco_hip.so``).
 """
 from .sparse import SparseTensor  # noqa: F401
-from .ops import khop, matmul, max_aggregate, spmm  # noqa: F401
+from .ops import khop, matmul, max_aggregate, pair_gather, spmm  # noqa: F401
 
 __version__ = "0.1.0"
