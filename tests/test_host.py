@@ -70,3 +70,22 @@ def test_module_state_dict_keys_match_reference():
     assert sorted(GCNConv(8, 4).state_dict()) == ["bias", "lin.weight"]
     assert sorted(SGConv(8, 4, K=2).state_dict()) == ["lin.bias", "lin.weight"]
     assert SGConv(8, 4).K == 3
+
+
+def test_negative_sampling_host_logic():
+    """negative_sampling is index bookkeeping in stock torch: no returned pair is an edge or a self pair, pairs are
+    distinct, and an (almost) complete graph yields fewer samples than asked for instead of looping forever."""
+    import numpy as np
+    import torch
+    from disco_amd.link_prediction import negative_sampling
+    n = 60
+    rng = np.random.default_rng(0)
+    ei = torch.from_numpy(rng.integers(0, n, (2, 400)))
+    neg = negative_sampling(ei, n, 900, torch.Generator().manual_seed(3)).numpy()
+    assert neg.shape == (2, 900)
+    pos = set((ei[0] * n + ei[1]).tolist())
+    keys = neg[0] * n + neg[1]
+    assert not (set(keys.tolist()) & pos) and len(set(keys.tolist())) == 900 and np.all(neg[0] != neg[1])
+    full = torch.tensor([[i, j] for i in range(6) for j in range(6) if i != j and (i, j) != (0, 1)]).T
+    few = negative_sampling(full, 6, 10, torch.Generator().manual_seed(1))
+    assert few.shape[1] <= 1 and all((int(a), int(b)) == (0, 1) for a, b in few.T)
