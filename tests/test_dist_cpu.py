@@ -32,7 +32,9 @@ def _oracle_spmm(adj, x, reduce, out):
     return out
 
 
-def _worker(rank, world, port, n, F, K, result_dir):
+def _worker(rank, world, port, n, F, K, result_dir, dense=False):
+    if dense:
+        os.environ["DISCO_DENSE_HALO"] = "1"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -41,11 +43,14 @@ def _worker(rank, world, port, n, F, K, result_dir):
         rowptr, col, val = random_csr(n, n, 6, seed=77, hubs=[(2, 400)], weighted=True)
         x = np.random.default_rng(5).standard_normal((n, F)).astype(np.float32)
         offs = balanced_row_offsets(torch.from_numpy(rowptr), world)
+        if dense:
+            offs = [g * (n // world) for g in range(world + 1)]       # the dense variant needs equal row blocks
         lo, hi = offs[rank], offs[rank + 1]
         rp = torch.from_numpy(rowptr[lo:hi + 1] - rowptr[lo])
         sl = slice(rowptr[lo], rowptr[hi])
         part = RowPartition(rp, torch.from_numpy(col[sl]), torch.from_numpy(val[sl]), offs, rank, world, spmm_fn=_oracle_spmm)
         assert part.adj_int.nnz() + part.adj_halo.nnz() == rowptr[hi] - rowptr[lo]
+        assert part.dense == dense
         cur = torch.from_numpy(x[lo:hi].copy())
         for _ in range(K):
             out = torch.empty_like(cur)
@@ -78,3 +83,17 @@ def test_row_partition_matches_global_oracle(world, tmp_path):
     # need-only exchange: what is received is what somebody sent
     halo = np.array([np.load(tmp_path / f"halo{r}.npy") for r in range(world)])
     assert halo[:, 0].sum() == halo[:, 1].sum() and halo[:, 0].max() < n
+
+
+def test_dense_halo_variant_matches_global_oracle(tmp_path):
+    """DISCO_DENSE_HALO=1: the exchange is one all-gather of X and the halo block indexes it by global column id."""
+    n, F, K, world = 300, 9, 2, 3
+    mp.spawn(_worker, args=(world, _free_port(), n, F, K, str(tmp_path), True), nprocs=world, join=True)
+    rowptr, col, val = random_csr(n, n, 6, seed=77, hubs=[(2, 400)], weighted=True)
+    x = np.random.default_rng(5).standard_normal((n, F)).astype(np.float32)
+    ref = orc.khop_csr(rowptr, col, val, x, K, np.float64)
+    got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(world)])
+    bound = np.abs(x).astype(np.float64)
+    for _ in range(K):
+        bound = orc.spmm_abs_bound(rowptr, col, val, bound)
+    assert np.all(np.abs(got - ref) <= 1e-5 * K * bound + 1e-30)

@@ -16,7 +16,9 @@ from test_dist_cpu import _free_port
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, n, F, K, result_dir):
+def _worker(rank, world, port, n, F, K, result_dir, dense=False):
+    if dense:
+        os.environ["DISCO_DENSE_HALO"] = "1"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -26,10 +28,13 @@ def _worker(rank, world, port, n, F, K, result_dir):
         rowptr, col, val = random_csr(n, n, 9, seed=78, hubs=[(3, 2600), (n - 2, 900)], weighted=True)
         x = np.random.default_rng(6).standard_normal((n, F)).astype(np.float32)
         offs = balanced_row_offsets(torch.from_numpy(rowptr), world)
+        if dense:
+            offs = [g * (n // world) for g in range(world + 1)]
         lo, hi = offs[rank], offs[rank + 1]
         rp = torch.from_numpy(rowptr[lo:hi + 1] - rowptr[lo]).to(dev)
         sl = slice(rowptr[lo], rowptr[hi])
         part = RowPartition(rp, torch.from_numpy(col[sl]).to(dev), torch.from_numpy(val[sl]).to(dev), offs, rank, world)
+        assert part.dense == dense
         ld = (F + 31) // 32 * 32
         cur = torch.zeros((hi - lo, ld), device=dev)[:, :F]
         cur.copy_(torch.from_numpy(x[lo:hi]))
@@ -44,10 +49,10 @@ def _worker(rank, world, port, n, F, K, result_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("F", [40, 602])
-def test_two_ranks_one_gpu_matches_global_oracle(F, tmp_path):
+@pytest.mark.parametrize("F,dense", [(40, False), (602, False), (602, True)])
+def test_two_ranks_one_gpu_matches_global_oracle(F, dense, tmp_path):
     n, K, world = 3000, 2, 2
-    mp.spawn(_worker, args=(world, _free_port(), n, F, K, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, F, K, str(tmp_path), dense), nprocs=world, join=True)
     rowptr, col, val = random_csr(n, n, 9, seed=78, hubs=[(3, 2600), (n - 2, 900)], weighted=True)
     x = np.random.default_rng(6).standard_normal((n, F)).astype(np.float32)
     ref = orc.khop_csr(rowptr, col, val, x, K, np.float64)
