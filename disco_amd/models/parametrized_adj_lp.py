@@ -21,44 +21,43 @@ _VARIANTS = {"transductive": 0, "inductive": 1, "sampled": 2}
 
 
 class PGE_Edge(nn.Module):
+    """Pair scorer MLP.  Interface contract taken from the reference (constructor arguments, ``forward`` /
+    ``inference`` signatures, parameter names ``layers.<i>`` / ``bns.<i>`` so that saved
+    ``pge_aggr_max_*.pt`` files load, /root/reference/LargeScaleCondensing.py:391-394): ``nlayers`` linear
+    layers ``2*nfeat -> nhid -> ... -> 1`` with BatchNorm1d + ReLU after every layer but the last, sigmoid on
+    the single logit."""
 
     def __init__(self, nfeat, nhid=256, nlayers=3, device=None, args=None):
-        super(PGE_Edge, self).__init__()
-        self.layers = nn.ModuleList([])
-        self.layers.append(nn.Linear(nfeat * 2, nhid))
-        self.bns = torch.nn.ModuleList()
-        self.bns.append(nn.BatchNorm1d(nhid))
-        for i in range(nlayers - 2):
-            self.layers.append(nn.Linear(nhid, nhid))
-            self.bns.append(nn.BatchNorm1d(nhid))
-        self.layers.append(nn.Linear(nhid, 1))
-        self.device = device
-        self.reset_parameters()
-        self.cnt = 0
-        self.args = args
+        super().__init__()
+        if nlayers < 2:
+            raise ValueError("PGE_Edge needs at least an input and an output layer")
+        widths = [2 * nfeat] + [nhid] * (nlayers - 1) + [1]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(widths[:-1], widths[1:]))
+        self.bns = nn.ModuleList(nn.BatchNorm1d(nhid) for _ in range(nlayers - 1))
+        self.device, self.args, self.cnt = device, args, 0
+        self.reset_parameters()      # the reference re-draws the initial weights once more after construction
+
+    def reset_parameters(self):
+        for m in list(self.layers) + list(self.bns):
+            m.reset_parameters()
+
+    def logits(self, edge_embed: torch.Tensor) -> torch.Tensor:
+        h = edge_embed
+        for lin, bn in zip(self.layers[:-1], self.bns):
+            h = F.relu(bn(lin(h)))
+        return self.layers[-1](h).reshape(-1)
 
     def forward(self, edge_embed, inference=False):
-        for ix, layer in enumerate(self.layers):
-            edge_embed = layer(edge_embed)
-            if ix != len(self.layers) - 1:
-                edge_embed = self.bns[ix](edge_embed)
-                edge_embed = F.relu(edge_embed)
-        pred = torch.sigmoid(edge_embed).reshape(-1)
-        return pred
+        """Edge probability of every row ``[z_src || z_dst]`` of ``edge_embed`` (``inference`` is accepted
+        for call compatibility and changes nothing, as in the reference)."""
+        return torch.sigmoid(self.logits(edge_embed))
 
     @torch.no_grad()
     def inference(self, edge_embed):
+        """Eval-mode (running BatchNorm statistics) forward; leaves the module in eval mode like the
+        reference's ``inference`` does (parametrized_adj_lp.py:41-44)."""
         self.eval()
-        pred = self.forward(edge_embed, inference=True)
-        return pred
-
-    def reset_parameters(self):
-        def weight_reset(m):
-            if isinstance(m, nn.Linear):
-                m.reset_parameters()
-            if isinstance(m, nn.BatchNorm1d):
-                m.reset_parameters()
-        self.apply(weight_reset)
+        return self.forward(edge_embed, inference=True)
 
     # ---- HIP path -------------------------------------------------------------------------------
     def _prepare(self, Z: torch.Tensor):

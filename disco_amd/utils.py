@@ -26,15 +26,16 @@ def maybe_num_nodes(edge_index: torch.Tensor, num_nodes: Optional[int] = None) -
 
 
 def add_self_loops(edge_index, edge_weight=None, fill_value=1, num_nodes=None):
-    """/root/reference/utils.py:457-471: append one loop per node (no de-duplication)."""
-    loop_index = torch.arange(0, num_nodes, dtype=torch.long, device=edge_index.device)
-    loop_index = loop_index.unsqueeze(0).repeat(2, 1)
-    if edge_weight is not None:
-        assert edge_weight.numel() == edge_index.size(1)
-        loop_weight = edge_weight.new_full((num_nodes,), fill_value)
-        edge_weight = torch.cat([edge_weight, loop_weight], dim=0)
-    edge_index = torch.cat([edge_index, loop_index], dim=1)
-    return edge_index, edge_weight
+    """Interface of /root/reference/utils.py:457-471: one (i, i) edge per node is APPENDED after the given edges
+    (existing loops are kept, nothing is de-duplicated); weights, when given, get ``fill_value`` for the loops."""
+    n = maybe_num_nodes(edge_index, num_nodes)
+    ids = torch.arange(n, dtype=torch.long, device=edge_index.device)
+    out_index = torch.cat((edge_index, torch.stack((ids, ids))), dim=1)
+    if edge_weight is None:
+        return out_index, None
+    if edge_weight.numel() != edge_index.size(1):
+        raise ValueError("edge_weight must have one entry per edge")
+    return out_index, torch.cat((edge_weight, torch.full_like(edge_weight[:1], fill_value).expand(n)))
 
 
 def add_remaining_self_loops(edge_index, edge_weight, fill_value, num_nodes):
@@ -205,15 +206,12 @@ def normalize_adj_tensor(adj: torch.Tensor, sparse: bool = False):
         out = normalize_adj_csr(st)
         row, col, val = out.coo()
         return torch.sparse_coo_tensor(torch.stack([row, col]), val, adj.shape).coalesce()
-    device = adj.device
-    mx = adj + torch.eye(adj.shape[0]).to(device)
-    rowsum = mx.sum(1)
-    r_inv = rowsum.pow(-1 / 2).flatten()
-    r_inv[torch.isinf(r_inv)] = 0.
-    r_mat_inv = torch.diag(r_inv)
-    mx = r_mat_inv @ mx
-    mx = mx @ r_mat_inv
-    return mx
+    # dense branch: r = rowsum(A + I)^-1/2 with inf -> 0, result diag(r) (A + I) diag(r) -- the two diagonal
+    # products are row / column scalings (same float32 products as multiplying by the diagonal matrices)
+    a_hat = adj + torch.eye(adj.shape[0], dtype=adj.dtype, device=adj.device)
+    r = a_hat.sum(dim=1).pow(-0.5)
+    r = torch.where(torch.isinf(r), torch.zeros_like(r), r)
+    return (r.unsqueeze(1) * a_hat) * r.unsqueeze(0)
 
 
 def to_undirected(edge_index: torch.Tensor, edge_attr=None, num_nodes: Optional[int] = None) -> torch.Tensor:

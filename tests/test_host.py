@@ -89,3 +89,49 @@ def test_negative_sampling_host_logic():
     full = torch.tensor([[i, j] for i in range(6) for j in range(6) if i != j and (i, j) != (0, 1)]).T
     few = negative_sampling(full, 6, 10, torch.Generator().manual_seed(1))
     assert few.shape[1] <= 1 and all((int(a), int(b)) == (0, 1) for a, b in few.T)
+
+
+def test_add_self_loops_and_dense_normalisation_contract():
+    """add_self_loops appends n loops after the edges (reference interface, utils.py:457-471); the dense branch of
+    normalize_adj_tensor equals diag(r) (A + I) diag(r) with r = rowsum^-1/2 and inf -> 0 (utils.py:486-493)."""
+    from disco_amd import utils
+    ei = torch.tensor([[0, 2, 2], [1, 2, 0]])
+    w = torch.tensor([0.5, 2.0, 3.0])
+    ei2, w2 = utils.add_self_loops(ei, w, fill_value=7, num_nodes=4)
+    assert ei2.tolist() == [[0, 2, 2, 0, 1, 2, 3], [1, 2, 0, 0, 1, 2, 3]] and w2.tolist() == [0.5, 2.0, 3.0, 7, 7, 7, 7]
+    ei3, w3 = utils.add_self_loops(ei, None, num_nodes=3)
+    assert w3 is None and ei3.shape == (2, 6)
+    with pytest.raises(ValueError):
+        utils.add_self_loops(ei, w[:2], num_nodes=3)
+    g = torch.Generator().manual_seed(0)
+    a = (torch.rand(9, 9, generator=g) < 0.3).float()
+    a[4] = 0
+    a[4, 4] = -1.0                                    # row sum of A + I is 0 -> r = inf -> 0
+    got = utils.normalize_adj_tensor(a)
+    mx = a + torch.eye(9)
+    r = mx.sum(1).pow(-0.5)
+    r[torch.isinf(r)] = 0
+    assert torch.equal(got, torch.diag(r) @ mx @ torch.diag(r)) and float(got[4].abs().sum()) == 0.0
+
+
+def test_pge_edge_shell_contract():
+    """Constructor / state_dict contract of the scorer's torch shell and that `inference` is the
+    eval-mode sigmoid of the logits the oracle restates."""
+    from disco_amd.models.parametrized_adj_lp import PGE_Edge
+    m = PGE_Edge(nfeat=5, nhid=16, nlayers=3)
+    keys = sorted(m.state_dict())
+    assert keys == sorted([f"layers.{i}.{p}" for i in range(3) for p in ("weight", "bias")] +
+                          [f"bns.{i}.{p}" for i in range(2) for p in ("weight", "bias", "running_mean", "running_var",
+                                                                      "num_batches_tracked")])
+    assert m.layers[0].in_features == 10 and m.layers[2].out_features == 1
+    assert len(PGE_Edge(4, nlayers=4).layers) == 4 and len(PGE_Edge(4, nlayers=4).bns) == 3
+    with torch.no_grad():
+        for bn in m.bns:
+            bn.running_mean.normal_()
+            bn.running_var.uniform_(0.5, 2.0)
+    e = torch.randn(33, 10)
+    p = m.inference(e)
+    assert not m.training and p.shape == (33,)
+    params = {k: v.numpy() for k, v in m.state_dict().items()}
+    ref = orc.sigmoid(orc.pge_edge_logits(params, e.numpy(), np.float64))
+    assert np.allclose(p.numpy(), ref, atol=2e-6)
