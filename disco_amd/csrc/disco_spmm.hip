@@ -205,13 +205,31 @@ template <int VEC> __device__ __forceinline__ typename Vec<VEC>::type vdiv(typen
   }
 }
 
+// Store one vector of an output row; `valid` = columns left in the row at this vector's position.  The last
+// vector of a row whose width is not a multiple of VEC is written element by element, so nothing beyond
+// column F - 1 of y is ever touched (y may be a column view of a wider live matrix).
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ dst, const typename Vec<VEC>::type& a, int valid) {
+  if constexpr (VEC == 1) {
+    *dst = a;
+  } else {
+    if (valid >= VEC) {
+      *reinterpret_cast<typename Vec<VEC>::type*>(dst) = a;
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC - 1; ++i)
+        if (i < valid) dst[i] = a[i];
+    }
+  }
+}
+
 // ---- rows below the hub threshold: one group of G lanes per row ---------------------------------
 template <int VEC, int G, int NV, int OP, bool HASVAL, bool A24>
 __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                    const float* __restrict__ val, const float* __restrict__ x,
                                                    int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
                                                    const uint32_t* __restrict__ perm, int64_t first, int64_t count,
-                                                   int flags) {
+                                                   int flags, int fcols) {
   typedef typename Vec<VEC>::type V;
   constexpr int RPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -245,7 +263,7 @@ __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ r
         if (mean && !empty) a = vdiv<VEC>(a, cnt);
         if (accum) a = *dst + a;  // y += A x: the earlier (interior) part first, then this part
       }
-      *dst = a;
+      store_vec<VEC>(reinterpret_cast<float*>(dst), a, fcols - idx * VEC);
     }
   }
 }
@@ -264,7 +282,7 @@ __global__ __launch_bounds__(256, NV == 1 ? 6 : 1) void k_spmm_rows_win(const in
                                                        int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
                                                        const uint32_t* __restrict__ perm, int64_t first, int64_t count,
                                                        const uint32_t* __restrict__ wbeg, const uint32_t* __restrict__ wend,
-                                                       int first_window, int last_window, int flags, int rpg) {
+                                                       int first_window, int last_window, int flags, int rpg, int fcols) {
   typedef typename Vec<VEC>::type V;
   constexpr int RPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -335,7 +353,7 @@ __global__ __launch_bounds__(256, NV == 1 ? 6 : 1) void k_spmm_rows_win(const in
             V a = acc[v];
             if (cnt > 0.0f) a = vdiv<VEC>(a, cnt);
             if (empty_row) a = 0.0f;
-            *reinterpret_cast<V*>(yr + (int64_t)idx * VEC) = a;
+            store_vec<VEC>(yr + (int64_t)idx * VEC, a, fcols - idx * VEC);
           }
         }
       }
@@ -352,7 +370,7 @@ __global__ __launch_bounds__(512) void k_spmm_hub(const int64_t* __restrict__ ro
                                                   const int64_t* __restrict__ piece_begin,
                                                   const int64_t* __restrict__ piece_end,
                                                   const int32_t* __restrict__ piece_slot, float* __restrict__ partial,
-                                                  int64_t ldp, int flags) {
+                                                  int64_t ldp, int flags, int fcols) {
   typedef typename Vec<VEC>::type V;
   constexpr int NG = 512 / G;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -391,7 +409,8 @@ __global__ __launch_bounds__(512) void k_spmm_hub(const int64_t* __restrict__ ro
       if ((flags & FLAG_MEAN) && slot < 0) s = vdiv<VEC>(s, cnt);
       if ((flags & FLAG_ACCUM) && slot < 0) s = *out + s;
     }
-    *out = s;
+    // partial rows live in the caller's workspace (ldp is a multiple of 4): whole vectors; y: masked tail
+    store_vec<VEC>(reinterpret_cast<float*>(out), s, slot < 0 ? fcols - i * VEC : VEC);
   }
 }
 
@@ -435,7 +454,7 @@ __global__ __launch_bounds__(256, 4) void k_spmm_sweep(const int64_t* __restrict
                                                        int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
                                                        const uint32_t* __restrict__ perm, int64_t first, int64_t count,
                                                        const uint32_t* __restrict__ wptr, int64_t cp, int P,
-                                                       int64_t n_batches, int flags) {
+                                                       int64_t n_batches, int flags, int fcols) {
   constexpr int R = 16;
   const int lane = threadIdx.x & 63;
   const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -532,7 +551,7 @@ __global__ __launch_bounds__(256, 4) void k_spmm_sweep(const int64_t* __restrict
         f4* dst = reinterpret_cast<f4*>(y + rs * ldy + (int64_t)lane * 4);
         if ((flags & FLAG_MEAN) && ne > nb) a = vdiv<4>(a, (float)(ne - nb));
         if (flags & FLAG_ACCUM) a = *dst + a;
-        *dst = a;
+        store_vec<4>(reinterpret_cast<float*>(dst), a, fcols - lane * 4);
       }
     }
   }
@@ -579,7 +598,7 @@ __global__ __launch_bounds__(256) void k_spmm_psync(const int64_t* __restrict__ 
                                                     int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
                                                     const uint32_t* __restrict__ perm, int64_t first, int64_t count,
                                                     const uint32_t* __restrict__ wptr, int64_t cp, int P, int flags,
-                                                    int n_iter, int* __restrict__ prog, int target, int poll_cap) {
+                                                    int n_iter, int* __restrict__ prog, int target, int poll_cap, int fcols) {
   typedef typename Vec<VEC>::type V;
   constexpr int R = 8;
   constexpr int RPW = 64 / G;
@@ -642,7 +661,7 @@ __global__ __launch_bounds__(256) void k_spmm_psync(const int64_t* __restrict__ 
           if (cnt > 0.0f) a = vdiv<VEC>(a, cnt);
         }
         if (flags & FLAG_ACCUM) a = *dst + a;
-        *dst = a;
+        store_vec<VEC>(reinterpret_cast<float*>(dst), a, fcols - gl * VEC);
       }
     }
   }
@@ -706,7 +725,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
                          reinterpret_cast<const int32_t*>(a.sched + s.off_piece_row),
                          reinterpret_cast<const int64_t*>(a.sched + s.off_piece_begin),
                          reinterpret_cast<const int64_t*>(a.sched + s.off_piece_end),
-                         reinterpret_cast<const int32_t*>(a.sched + s.off_piece_slot), a.partial, a.ldp, mean);
+                         reinterpret_cast<const int32_t*>(a.sched + s.off_piece_slot), a.partial, a.ldp, mean, (int)a.F);
       if (s.n_multi_rows > 0) {
         hipLaunchKernelGGL((k_hub_combine<OP>), dim3((unsigned)s.n_multi_rows), dim3(256), 0, a.stream, a.rowptr,
                            reinterpret_cast<const int32_t*>(a.sched + s.off_multi_row),
@@ -743,7 +762,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
           const int cap = tuning().psync_polls > 0 ? tuning().psync_polls : 256;
           hipLaunchKernelGGL((k_spmm_psync<VEC, G, HASVAL, A24>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
                              a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, wptr, s.sweep_count_padded, P, mean,
-                             n_iter, prog, target, cap);
+                             n_iter, prog, target, cap, (int)a.F);
           swept = true;
         }
       }
@@ -762,7 +781,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       for (int w = 0; w < P; ++w) {
         hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, OP, HASVAL, A24>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
                            a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, wptr + (int64_t)w * s.sweep_count_padded,
-                           wptr + (int64_t)(w + 1) * s.sweep_count_padded, w == 0, w == P - 1, mean, rpg);
+                           wptr + (int64_t)(w + 1) * s.sweep_count_padded, w == 0, w == P - 1, mean, rpg, (int)a.F);
       }
       swept = true;
     }
@@ -776,7 +795,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       if (blocks > cap) blocks = cap;
       hipLaunchKernelGGL((k_spmm_sweep<HASVAL>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col, a.val, a.x,
                          a.ldx, a.y, a.ldy, nvec, perm, first, count, reinterpret_cast<const uint32_t*>(s.sweep_ws),
-                         s.sweep_count_padded, (int)s.sweep_windows, n_batches, mean);
+                         s.sweep_count_padded, (int)s.sweep_windows, n_batches, mean, (int)a.F);
       swept = true;
     }
   }
@@ -784,7 +803,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
     int64_t blocks = (count + 4 * RPW - 1) / (4 * RPW);
     if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
     hipLaunchKernelGGL((k_spmm_rows<VEC, G, NV, OP, HASVAL, A24>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
-                       a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, mean);
+                       a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, mean, (int)a.F);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_last_hip_error((int)e); return DISCO_EHIP; }

@@ -80,7 +80,13 @@ class MessagePassing(torch.nn.Module):
         n_src = x.shape[0]
         n_dst = n_src if size is None else (size[1] if size[1] is not None else n_src)
         struct, perm = self._edge_cache.get(edge_index, n_src, n_dst)
+        if edge_weight is not None and edge_weight.requires_grad and torch.is_grad_enabled():
+            # the reference detaches the condensed graph's weights (LargeScaleCondensing.py:309-310); a gradient
+            # that would silently be dropped is an error here
+            raise NotImplementedError("edge_weight.requires_grad: this path returns gradients for x only")
         w = None if edge_weight is None else edge_weight[perm]
+        if struct.device.type == "cuda" and struct.size(0) > 0:
+            struct.schedule(feat=x.shape[1])     # built once on the cached structure, inherited by set_value
         adj = struct.set_value(w)
         reduce = "sum" if self.aggr == "add" else self.aggr
         if reduce == "max" and w is not None:

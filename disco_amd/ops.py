@@ -49,6 +49,19 @@ def _padded_empty(n: int, F: int, device, pad: int = 4) -> torch.Tensor:
     return torch.empty((n, ld), dtype=torch.float32, device=device)[:, :F]
 
 
+def _hub_workspace(adj: SparseTensor, info, F: int, lib, device):
+    """Partial-row workspace of the hub kernels, kept on the adjacency and grown on demand (one allocation per
+    graph instead of one per call).  Calls that overlap on different streams must not share an adjacency."""
+    need = int(lib.disco_spmm_workspace_bytes(info, F))
+    if not need:
+        return None, 0
+    ws = adj._hub_ws
+    if ws is None or ws.numel() < need or ws.device != device:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        adj._hub_ws = ws
+    return ws, ws.numel()
+
+
 def spmm_raw(adj: SparseTensor, x: torch.Tensor, reduce: str = "sum", out: Optional[torch.Tensor] = None,
              use_schedule: bool = True) -> torch.Tensor:
     """y = reduce_e val[e] * x[col[e]] through disco_spmm_csr_f32 (no autograd)."""
@@ -70,10 +83,7 @@ def spmm_raw(adj: SparseTensor, x: torch.Tensor, reduce: str = "sum", out: Optio
         if use_schedule and n > 0:
             ws, info = adj.schedule(feat=F)
             ws_ptr, info_ref = _lib.ptr(ws), info
-            need = lib.disco_spmm_workspace_bytes(info, F)
-            if need:
-                sws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
-                sws_bytes = sws.numel()
+            sws, sws_bytes = _hub_workspace(adj, info, F, lib, x.device)
         _lib.check(lib.disco_spmm_csr_f32(_lib.ptr(adj._rowptr), _lib.ptr(adj._col32), _lib.ptr(val), n,
                                           _lib.ptr(x), x.stride(0), _lib.ptr(out), out.stride(0), F, _REDUCE[reduce],
                                           ws_ptr, info_ref, _lib.ptr(sws), sws_bytes, stream), "disco_spmm_csr_f32")
@@ -146,10 +156,7 @@ def khop(adj: SparseTensor, x: torch.Tensor, K: int, n_col_slices: int = 1, out:
         if use_schedule and n > 0:
             ws, info = adj.schedule(feat=F)
             ws_ptr, info_ref = _lib.ptr(ws), info
-            nb = lib.disco_spmm_workspace_bytes(info, F)
-            if nb:
-                sws = torch.empty(int(nb), dtype=torch.uint8, device=x.device)
-                sws_bytes = sws.numel()
+            sws, sws_bytes = _hub_workspace(adj, info, F, lib, x.device)
         _lib.check(lib.disco_khop_csr_f32(_lib.ptr(adj._rowptr), _lib.ptr(adj._col32), _lib.ptr(val), n, K,
                                           _lib.ptr(x), x.stride(0), _lib.ptr(out), out.stride(0), _lib.ptr(t0),
                                           _lib.ptr(t1), ldt, F, n_col_slices, ws_ptr, info_ref, _lib.ptr(sws),

@@ -24,6 +24,7 @@ WIN_COLS = 128           # column block width of the windowed launches (libdisco
 WINDOW_BYTES = 5632 << 10   # 5.5 MiB: flat optimum 5-6 MiB on Reddit (profiles/r1/tune_window_fine.log)
 
 
+_SWEEP_FIELDS = ("sweep_ws", "sweep_windows", "sweep_window_rows", "sweep_count_padded", "sweep_n_cols")
 WIN_HUB_THRESHOLD, WIN_HUB_PIECE = 8192, 4096   # hub split used with windowed launches (tune_hub_windowed.log)
 
 
@@ -94,6 +95,18 @@ class _Storage:
         return self._o._sizes
 
 
+class _StructCache:
+    """Caches that depend on the (immutable) structure only and are therefore shared by every ``set_value`` copy:
+    the transposed structure and the permutation that carries values into it."""
+    __slots__ = ("t_struct", "t_perm", "sched", "sweep")
+
+    def __init__(self):
+        self.t_struct: Optional["SparseTensor"] = None
+        self.t_perm: Optional[torch.Tensor] = None
+        self.sched = {}     # (hub_threshold, hub_piece) -> (workspace tensor, ScheduleInfo template without window table)
+        self.sweep = {}     # ((hub_threshold, hub_piece), window_rows) -> (workspace tensor | None, window fields)
+
+
 class SparseTensor:
     def __init__(self, row: Optional[torch.Tensor] = None, rowptr: Optional[torch.Tensor] = None,
                  col: Optional[torch.Tensor] = None, value: Optional[torch.Tensor] = None,
@@ -130,12 +143,30 @@ class SparseTensor:
         self._col32 = col.to(torch.int32).contiguous()
         self._value = None if value is None else value.contiguous()
         self._sizes = sparse_sizes
-        self._sched = None          # (ws tensor, ScheduleInfo)
+        self._init_caches()
+
+    def _init_caches(self):
+        self._sched = None          # (ws tensor [immutable, shared by set_value copies], ScheduleInfo [own copy])
         self._sched_key = None
         self._sched_auto = False
         self._sweep = None          # (window_rows, workspace tensor or None)
+        self._sweep_force: Optional[bool] = None   # sticky schedule(sweep=True/False) choice
+        self._window_bytes: Optional[int] = None   # sticky schedule(window_bytes=) override
+        self._hub_ws: Optional[torch.Tensor] = None    # partial-row workspace of the hub kernels (grown on demand)
         self._t: Optional["SparseTensor"] = None
+        self._shared = _StructCache()
         self.storage = _Storage(self)
+
+    @classmethod
+    def _from_parts(cls, rowptr: torch.Tensor, col32: torch.Tensor, value: Optional[torch.Tensor],
+                    sparse_sizes: Tuple[int, int]) -> "SparseTensor":
+        """Wrap already validated CSR arrays (int64 rowptr, int32 col) without any device read-back."""
+        out = cls.__new__(cls)
+        out._rowptr, out._col32 = rowptr, col32
+        out._value = None if value is None else value.contiguous()
+        out._sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
+        out._init_caches()
+        return out
 
     # ---- constructors ---------------------------------------------------------------------
     @classmethod
@@ -200,9 +231,18 @@ class SparseTensor:
         return self._value is not None
 
     def set_value(self, value: Optional[torch.Tensor], layout: Optional[str] = None) -> "SparseTensor":
-        out = SparseTensor(rowptr=self._rowptr, col=self._col32, value=value, sparse_sizes=self._sizes, is_sorted=True)
-        out._sched, out._sched_key, out._sweep = self._sched, self._sched_key, self._sweep
-        out._sched_auto = getattr(self, "_sched_auto", False)
+        """Same structure, other values.  The copy gets its OWN host-side schedule info (the struct is mutated
+        when a window table is attached or detached); the device workspaces it points to are immutable once
+        built and stay referenced by every object whose info points at them."""
+        if value is not None and value.numel() != self.nnz():
+            raise ValueError("value must have one entry per stored element")
+        out = SparseTensor._from_parts(self._rowptr, self._col32, value, self._sizes)
+        if self._sched is not None:
+            ws, info = self._sched
+            out._sched = (ws, _lib.ScheduleInfo.from_buffer_copy(info))
+        out._sched_key, out._sched_auto = self._sched_key, self._sched_auto
+        out._sweep, out._sweep_force, out._window_bytes = self._sweep, self._sweep_force, self._window_bytes
+        out._shared = self._shared
         return out
 
     def fill_value(self, fill: float, dtype=torch.float32) -> "SparseTensor":
@@ -236,23 +276,50 @@ class SparseTensor:
 
     # ---- transpose ------------------------------------------------------------------------------
     def t(self) -> "SparseTensor":
-        """Transposed matrix as CSR (row-major sorted, stable in the original entry order)."""
+        """Transposed matrix as CSR (row-major sorted, stable in the original entry order).  The transposed
+        structure and the value permutation are built once per structure and shared by ``set_value`` copies
+        (the backward of every training step on the condensed graph re-uses them)."""
         if self._t is None:
-            row = self._row()
-            col = self._col64()
-            out = SparseTensor(row=col, col=row, value=self._value, sparse_sizes=(self._sizes[1], self._sizes[0]))
+            sh = self._shared
+            if sh.t_struct is None:
+                sizes_t = (self._sizes[1], self._sizes[0])
+                nnz = self.nnz()
+                row, col = self._row(), self._col64()
+                if self._col32.is_cuda and 0 < nnz < 2 ** 31:
+                    # the stable device sort carries a 32-bit payload unchanged: send the entry index through it
+                    ids = torch.arange(nnz, dtype=torch.int32, device=self.device).view(torch.float32)
+                    rp, c32, pv = coo_to_csr(col, row, ids, sizes_t, dup="keep")
+                    perm = pv.view(torch.int32)
+                else:
+                    perm = torch.argsort(col * max(self._sizes[0], 1) + row, stable=True)
+                    counts = torch.bincount(col, minlength=sizes_t[0])
+                    rp = torch.zeros(sizes_t[0] + 1, dtype=torch.int64, device=self.device)
+                    torch.cumsum(counts, 0, out=rp[1:])
+                    c32 = row[perm].to(torch.int32)
+                sh.t_struct, sh.t_perm = SparseTensor._from_parts(rp, c32.contiguous(), None, sizes_t), perm
+            out = sh.t_struct.set_value(None if self._value is None else torch.index_select(self._value, 0, sh.t_perm))
             out._t = self
             self._t = out
         return self._t
 
     # ---- device-side schedule -------------------------------------------------------------------
-    def schedule(self, hub_threshold: int = 0, hub_piece: int = 0, feat: Optional[int] = None, sweep: Optional[bool] = None):
+    def schedule(self, hub_threshold: int = 0, hub_piece: int = 0, feat: Optional[int] = None, sweep: Optional[bool] = None,
+                 window_bytes: Optional[int] = None):
         """Degree-binned schedule (device workspace + host info), built once per structure.
 
         With ``feat`` (the feature width about to be propagated) the L2-blocked sweep structure is
-        attached as well when the graph re-uses source rows enough for it to pay
-        (``sweep=None``: automatic; True / False force it)."""
+        attached as well when the graph re-uses source rows enough for it to pay (``sweep=None``: automatic, or
+        the last explicit choice; True / False force it and STAY in force for later ``schedule(feat=...)`` calls
+        such as the ones ``ops.spmm_raw`` makes).  ``window_bytes`` overrides the window size (sticky as well; tests)."""
         lib = _lib.load()
+        if sweep is None:
+            sweep = self._sweep_force
+        else:
+            self._sweep_force = sweep
+        if window_bytes is None:
+            window_bytes = self._window_bytes
+        else:
+            self._window_bytes = window_bytes
         if hub_threshold == 0 and hub_piece == 0:
             if self._sched is not None and getattr(self, "_sched_auto", False):
                 hub_threshold, hub_piece = self._sched_key      # keep the automatic choice made first
@@ -263,45 +330,60 @@ class SparseTensor:
         else:
             auto = False
         key = (hub_threshold, hub_piece)
+        sh = self._shared
         if self._sched is None or self._sched_key != key:
             assert self.device.type == "cuda", "schedules live on the GPU"
-            n, nnz = self._sizes[0], self.nnz()
-            with torch.cuda.device(self.device):
-                nbytes = lib.disco_schedule_workspace_bytes(n, nnz, hub_threshold, hub_piece)
-                ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
-                info = _lib.ScheduleInfo()
-                _lib.check(lib.disco_schedule_build(_lib.ptr(self._rowptr), n, nnz, hub_threshold, hub_piece,
-                                                    _lib.ptr(ws), ws.numel(), info, _lib.current_stream(self.device)),
-                           "disco_schedule_build")
-                # keep only the part the SpMM kernels read
-                keep = int(info.off_multi_first + 8 * (info.n_multi_rows + 2))
-                keep = min(max(keep, 256), ws.numel())
-                if keep < ws.numel() // 2:
-                    ws = ws[:keep].clone()
-            info.n_cols = self._sizes[1]      # every col[] entry is < sizes[1] (checked at construction)
-            self._sched, self._sched_key, self._sched_auto = (ws, info), key, auto
+            if key not in sh.sched:
+                n, nnz = self._sizes[0], self.nnz()
+                with torch.cuda.device(self.device):
+                    nbytes = lib.disco_schedule_workspace_bytes(n, nnz, hub_threshold, hub_piece)
+                    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+                    info = _lib.ScheduleInfo()
+                    _lib.check(lib.disco_schedule_build(_lib.ptr(self._rowptr), n, nnz, hub_threshold, hub_piece,
+                                                        _lib.ptr(ws), ws.numel(), info, _lib.current_stream(self.device)),
+                               "disco_schedule_build")
+                    # keep only the part the SpMM kernels read
+                    keep = int(info.off_multi_first + 8 * (info.n_multi_rows + 2))
+                    keep = min(max(keep, 256), ws.numel())
+                    if keep < ws.numel() // 2:
+                        ws = ws[:keep].clone()
+                info.n_cols = self._sizes[1]      # every col[] entry is < sizes[1] (checked at construction)
+                sh.sched[key] = (ws, info)
+            ws, tmpl = sh.sched[key]
+            # own copy of the host struct: attaching / detaching a window table mutates it
+            self._sched, self._sched_key, self._sched_auto = (ws, _lib.ScheduleInfo.from_buffer_copy(tmpl)), key, auto
             self._sweep = None
         ws, info = self._sched
         if feat is not None and sweep is not False:
-            window_rows = sweep_window_rows(feat)
-            built = getattr(self, "_sweep", None)
+            window_rows = sweep_window_rows(feat, window_bytes) if window_bytes else sweep_window_rows(feat)
+            built = self._sweep
             if built is None or built[0] != window_rows:
                 want = sweep if sweep is not None else self.sweep_pays(feat)
                 self._sweep = (window_rows, None)
                 info.sweep_ws, info.sweep_windows = None, 0
                 if want and self._sizes[0] > 0:
-                    with torch.cuda.device(self.device):
-                        nb = lib.disco_sweep_workspace_bytes(info, self._sizes[1], window_rows)
-                        if nb:
-                            sw = torch.empty(int(nb), dtype=torch.uint8, device=self.device)
-                            rc = lib.disco_sweep_build(_lib.ptr(self._rowptr), _lib.ptr(self._col32), _lib.ptr(ws), info,
-                                                       self._sizes[1], window_rows, _lib.ptr(sw), sw.numel(),
-                                                       _lib.current_stream(self.device))
-                            if rc == -2:      # columns not sorted inside the rows: plain kernel stays in use
-                                sw = None
-                            else:
-                                _lib.check(rc, "disco_sweep_build")
-                            self._sweep = (window_rows, sw)
+                    skey = (key, window_rows)
+                    if skey not in sh.sweep:
+                        sw, fields = None, None
+                        with torch.cuda.device(self.device):
+                            nb = lib.disco_sweep_workspace_bytes(info, self._sizes[1], window_rows)
+                            if nb:
+                                sw = torch.empty(int(nb), dtype=torch.uint8, device=self.device)
+                                rc = lib.disco_sweep_build(_lib.ptr(self._rowptr), _lib.ptr(self._col32), _lib.ptr(ws), info,
+                                                           self._sizes[1], window_rows, _lib.ptr(sw), sw.numel(),
+                                                           _lib.current_stream(self.device))
+                                if rc == -2:      # columns not sorted inside the rows: plain kernel stays in use
+                                    sw = None
+                                else:
+                                    _lib.check(rc, "disco_sweep_build")
+                                    fields = tuple(getattr(info, f) for f in _SWEEP_FIELDS)
+                        sh.sweep[skey] = (sw, fields)
+                    sw, fields = sh.sweep[skey]
+                    if sw is not None:
+                        for f, v in zip(_SWEEP_FIELDS, fields):
+                            setattr(info, f, v)
+                    # the object keeps the table alive as long as its info points at it
+                    self._sweep = (window_rows, sw)
         elif sweep is False:
             info.sweep_ws, info.sweep_windows = None, 0
             self._sweep = None

@@ -125,15 +125,18 @@ def test_strided_and_unaligned_operands():
     from disco_amd import ops
     rowptr, col, val = random_csr(300, 300, 10, seed=5, hubs=[(7, 2500)], weighted=True)
     adj = to_adj(rowptr, col, val, 300)
-    for F, ld in ((602, 602), (601, 601), (602, 608), (100, 100), (127, 127)):
+    for F, ld in ((602, 602), (601, 601), (602, 608), (601, 604), (100, 100), (127, 127), (127, 128), (5, 8)):
         x = np.random.default_rng(F).standard_normal((300, F)).astype(np.float32)
         buf = torch.zeros((300, ld), device=dev())
         buf[:, :F] = torch.from_numpy(x).to(dev())
         xd = buf[:, :F]
-        out = torch.full((300, ld), 7.0, device=dev())[:, :F]
+        full = torch.full((300, ld), 7.0, device=dev())
+        out = full[:, :F]
         y = ops.spmm_raw(adj, xd, "sum", out=out).cpu().numpy()
         y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x, want_bound=True)
         assert_fwd_close(y, y64, bound, what=f"F={F} ld={ld}")
+        # columns F.. of the caller's buffer belong to the caller: the last partial vector is stored masked
+        assert bool((full[:, F:] == 7.0).all()), f"F={F} ld={ld}: padding columns were written"
 
 
 @pytest.mark.parametrize("K,slices", [(1, 1), (2, 1), (2, 3), (3, 2), (4, 5)])
@@ -235,10 +238,10 @@ def test_full_size_properties_reddit_shaped():
     assert bool(((a1 - rs).abs() <= 1e-5 * rs.abs() + 1e-12).all())
     # same bits as the plain kernel (same hub split) on the rows the windowed kernel owns
     plain = adj.set_value(adj.storage.value())
-    plain._sched, plain._sweep = None, None
     ws_p, info_p = plain.schedule(int(info.hub_threshold), int(info.hub_piece), feat=F, sweep=False)
-    assert not info_p.sweep_ws
+    assert not info_p.sweep_ws and adj.schedule(feat=F)[1].sweep_ws, "a copy's choice must not leak into its parent"
     y_plain = ops.spmm_raw(plain, x, "sum")
+    assert not plain.schedule(feat=F)[1].sweep_ws, "sweep=False is sticky: spmm_raw must not re-attach the table"
     deg = adj.storage.rowptr()[1:] - adj.storage.rowptr()[:-1]
     keep = deg <= int(info.hub_threshold)
     assert int((~keep).sum()) == int(info.n_hub_rows) > 0
@@ -326,10 +329,11 @@ def test_sum_acc_accumulates_onto_existing_output(sweep):
     assert empty.any() and np.array_equal(out.cpu().numpy()[empty], y0[empty])      # rows without entries keep y0
 
 
-@pytest.mark.parametrize("ld", [602, 601])
+@pytest.mark.parametrize("ld", [602, 601, 604])
 def test_windowed_path_with_narrow_vectors(ld):
     """ld = 602: rows are only 8-byte aligned -> 64-bit gathers, still windowed; ld = 601: scalar loads, the
-    window table is ignored and the plain kernel runs.  Both must meet the forward-error bar."""
+    window table is ignored and the plain kernel runs; ld = 604: 128-bit gathers with a partial last vector
+    (F = 602), stored masked.  All must meet the forward-error bar and leave the padding columns alone."""
     from disco_amd import _lib, ops
     lib = _lib.load()
     n, F = 3000, min(ld, 602)
@@ -349,3 +353,51 @@ def test_windowed_path_with_narrow_vectors(ld):
     got = out.cpu().numpy()
     assert_fwd_close(got[:, :F], y64, bound, what=f"ld={ld}")
     assert np.all(got[:, F:] == 7.0)             # padding columns are never written
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
+def test_multi_window_resume_same_bits_as_plain(reduce):
+    """Several windows on a small graph (window of 64 source rows -> 47 windows): the running sum passes through
+    y between window launches and must come out with the same bits as the one-pass plain kernel."""
+    from disco_amd import ops
+    n, F = 3000, 96
+    rowptr, col, val = random_csr(n, n, 90, seed=77, hubs=[(5, 2900)], weighted=True)
+    x = torch.from_numpy(np.random.default_rng(4).standard_normal((n, F)).astype(np.float32)).to(dev())
+    plain = to_adj(rowptr, col, val, n)
+    _, ip = plain.schedule(8192, 4096, feat=F, sweep=False)
+    win = to_adj(rowptr, col, val, n)
+    _, iw = win.schedule(8192, 4096, feat=F, sweep=True, window_bytes=64 * 4 * F)
+    assert not ip.sweep_ws and iw.sweep_ws and iw.sweep_windows >= 3 and iw.n_hub_rows == ip.n_hub_rows == 0
+    y_p = ops.spmm_raw(plain, x, reduce)
+    y_w = ops.spmm_raw(win, x, reduce)
+    assert not plain.schedule(feat=F)[1].sweep_ws and win.schedule(feat=F)[1].sweep_windows == iw.sweep_windows
+    assert torch.equal(y_p, y_w)
+
+
+def test_set_value_copies_do_not_share_schedule_state():
+    """A set_value copy that attaches a window table for another feature width (and is then freed) must leave
+    its parent's schedule untouched: every object owns its host-side schedule info."""
+    import gc
+    from disco_amd import ops
+    n, F1, F2 = 4000, 128, 32
+    rowptr, col, val = random_csr(n, n, 80, seed=91, weighted=True)
+    base = to_adj(rowptr, col, val, n)
+    x1 = torch.from_numpy(np.random.default_rng(5).standard_normal((n, F1)).astype(np.float32)).to(dev())
+    x2 = torch.from_numpy(np.random.default_rng(6).standard_normal((n, F2)).astype(np.float32)).to(dev())
+    _, info = base.schedule(feat=F1, sweep=True, window_bytes=256 * 4 * F1)
+    windows, table = int(info.sweep_windows), int(info.sweep_ws)
+    y_ref = ops.spmm_raw(base, x1, "sum").clone()
+    child = base.set_value(None)
+    _, ci = child.schedule(feat=F2, sweep=True, window_bytes=97 * 4 * F2)
+    assert ci is not info and int(ci.sweep_windows) != windows
+    ops.spmm_raw(child, x2, "max")
+    off = base.set_value(base.storage.value())
+    off.schedule(feat=F1, sweep=False)
+    del child, ci, off
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = torch.full((1 << 24,), 0x7f7f7f7f, dtype=torch.int32, device=dev())   # re-use whatever was freed
+    _, again = base.schedule(feat=F1)
+    assert int(again.sweep_windows) == windows and int(again.sweep_ws) == table
+    assert torch.equal(ops.spmm_raw(base, x1, "sum"), y_ref)
+    del junk

@@ -29,7 +29,6 @@ for F in (41, 128, 256, 602):
         else:
             os.environ["DISCO_SWEEP"] = mode
         adj = base.set_value(base.storage.value())
-        adj._sched, adj._sweep = None, None
         ts = []
         for i in range(4):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -18,7 +18,7 @@ for deg in (25, 50, 100, 200):
         y = torch.empty((n, ld), device=dev)[:, :F]
         for mode in ("1", "0"):
             os.environ["DISCO_SWEEP"] = mode
-            adj = base.set_value(base.storage.value()); adj._sched, adj._sweep = None, None
+            adj = base.set_value(base.storage.value())
             ts = []
             for i in range(4):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
