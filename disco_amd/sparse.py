@@ -321,8 +321,8 @@ class SparseTensor:
         else:
             self._window_bytes = window_bytes
         if hub_threshold == 0 and hub_piece == 0:
-            if self._sched is not None and getattr(self, "_sched_auto", False):
-                hub_threshold, hub_piece = self._sched_key      # keep the automatic choice made first
+            if self._sched is not None:
+                hub_threshold, hub_piece = self._sched_key      # keep the choice made first (automatic or explicit)
             elif feat is not None and sweep is not False and (sweep or self.sweep_pays(feat)):
                 # windowed launches visit a row once per window, so only much longer rows need splitting
                 hub_threshold, hub_piece = WIN_HUB_THRESHOLD, WIN_HUB_PIECE

@@ -77,17 +77,23 @@ def gcn_norm(edge_index: Union[torch.Tensor, SparseTensor], edge_weight: Optiona
         _require_cuda(adj_t._col32, "gcn_norm")
         if add_self_loops:
             adj_t = fill_diag(adj_t, fill_value)
-        # float32 semantics of torch_sparse.sum / mul are restated through the float64 row-sum
-        # kernel (exact for the unit-weight graphs the dead branch would see), then scaled.
+        # float32 throughout, as torch_sparse computes it: sequential float32 row sums in CSR order, deg^-1/2 as
+        # 1/sqrt (two correctly rounded float32 ops = torch's pow_(-0.5)), inf -> 0, (val * dis[row]) * dis[col]
         n = adj_t.size(0)
-        with torch.cuda.device(adj_t.device):
-            s = _lib.current_stream(adj_t.device)
-            rs = torch.empty(n, dtype=torch.float64, device=adj_t.device)
+        dev = adj_t.device
+        with torch.cuda.device(dev):
+            s = _lib.current_stream(dev)
+            rs = torch.empty(n, dtype=torch.float64, device=dev)
             val = adj_t._value
+            if val is not None and val.dtype != torch.float32:
+                val = val.to(torch.float32)
             _lib.check(lib.disco_csr_rowsum_f64(_lib.ptr(adj_t._rowptr), _lib.ptr(val), n, 0, _lib.ptr(rs), s), "disco_csr_rowsum_f64")
-            out = torch.empty(adj_t.nnz(), dtype=torch.float32, device=adj_t.device)
-            _lib.check(lib.disco_gcn_norm_csr_f32(_lib.ptr(adj_t._rowptr), _lib.ptr(adj_t._col32), _lib.ptr(val), n, 0,
-                                                  _lib.ptr(rs), _lib.ptr(out), s), "disco_gcn_norm_csr_f32")
+            dis = rs.to(torch.float32)                      # exact: the kernel's sums are float32 values
+            _lib.check(lib.disco_inv_sqrt_f32(_lib.ptr(dis), n, s), "disco_inv_sqrt_f32")
+            row, col, _ = adj_t.coo()
+            out = torch.empty(adj_t.nnz(), dtype=torch.float32, device=dev)
+            _lib.check(lib.disco_gcn_norm_coo_apply_f32(_lib.ptr(row), _lib.ptr(col), _lib.ptr(val), adj_t.nnz(), _lib.ptr(dis),
+                                                        _lib.ptr(out), s), "disco_gcn_norm_coo_apply_f32")
         return adj_t.set_value(out)
 
     assert flow in ["source_to_target", "target_to_source"]

@@ -86,6 +86,37 @@ def gcn_norm_coo(edge_index, edge_weight=None, num_nodes=None, improved=False,
     return edge_index, out.astype(np.float32)
 
 
+def gcn_norm_sparse(row, col, val, n, add_self_loops=True, improved=False):
+    """/root/reference/utils.py:214-226: the SparseTensor branch of ``gcn_norm`` (dead code in the reference --
+    no driver passes a SparseTensor -- restated for the A2 row; torch_sparse's ``fill_diag`` / ``sum`` / ``mul``
+    are [upstream, recalled], parity unpinned).  float32 throughout:
+
+    * no values -> all ones (:217-218);
+    * ``fill_diag(adj_t, fill_value)``: the whole diagonal is set to ``fill_value`` -- existing diagonal entries
+      are replaced, missing ones inserted (:219-220);
+    * ``deg = sum(adj_t, dim=1)``: ROW sums, sequential float32 adds in CSR (row-major sorted) order (:221);
+    * ``deg^-0.5`` (torch CPU: ``1/sqrt``), inf -> 0 (:222-223);
+    * ``mul`` by ``dis[row]`` then by ``dis[col]`` (:224-225).
+    Input COO (any order, no duplicates); returns ``(row, col, val)`` row-major sorted.
+    """
+    row, col = np.asarray(row, dtype=np.int64), np.asarray(col, dtype=np.int64)
+    val = np.ones(len(row), np.float32) if val is None else np.asarray(val, dtype=np.float32)
+    if add_self_loops:
+        keep = row != col
+        d = np.arange(n, dtype=np.int64)
+        row, col = np.concatenate([row[keep], d]), np.concatenate([col[keep], d])
+        val = np.concatenate([val[keep], np.full(n, 2.0 if improved else 1.0, np.float32)])
+    order = np.lexsort((col, row))
+    row, col, val = row[order], col[order], val[order]
+    deg = np.zeros(n, np.float32)
+    for r, v in zip(row, val):                    # sequential float32 accumulation in CSR order
+        deg[r] = np.float32(deg[r] + v)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dis = np.float32(1.0) / np.sqrt(deg)
+    dis[np.isinf(dis)] = np.float32(0.0)
+    return row, col, ((val * dis[row]) * dis[col]).astype(np.float32)
+
+
 # --------------------------------------------------------------------------
 # A3: normalize_adj_tensor(adj, sparse=True)
 # --------------------------------------------------------------------------
