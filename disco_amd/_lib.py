@@ -41,6 +41,8 @@ _SIGNATURES = {
     "disco_spmm_workspace_bytes": (c_size_t, [C.POINTER(ScheduleInfo), c_int64]),
     "disco_spmm_csr_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                    c_int64, c_int, c_void_p, C.POINTER(ScheduleInfo), c_void_p, c_size_t, c_void_p]),
+    "disco_spmm_csr_f32_noalloc": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                           c_int64, c_int, c_void_p, C.POINTER(ScheduleInfo), c_void_p]),
     "disco_khop_csr_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p,
                                    c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
                                    C.POINTER(ScheduleInfo), c_void_p, c_size_t, c_void_p]),
@@ -67,6 +69,7 @@ _SIGNATURES = {
     "disco_pair_gather_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                       c_void_p, c_int64, c_void_p, c_void_p]),
 }
+NOALLOC_SCRATCH_BYTES = 16 << 20
 COO_SYMMETRISE, COO_DUP_KEEP, COO_DUP_SUM, COO_DUP_FIRST = 1, 0, 2, 4
 
 # symbols that may legitimately be absent from an older build (none at the moment)

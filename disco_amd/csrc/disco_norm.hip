@@ -213,6 +213,7 @@ extern "C" const char* disco_status_string(int status) {
     case DISCO_EUNSUPPORTED: return "unsupported shape";
     case DISCO_EWORKSPACE: return "workspace too small";
     case DISCO_EHIP: return "HIP runtime error";
+    case DISCO_ESCRATCH: return "problem exceeds the built-in scratch of the allocation-free entry point (DISCO_NOALLOC_SCRATCH_BYTES)";
     default: return "unknown status";
   }
 }

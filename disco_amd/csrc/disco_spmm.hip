@@ -981,6 +981,49 @@ extern "C" int disco_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, con
   return spmm_dispatch(a);
 }
 
+// ---- allocation-free entry point ------------------------------------------------------------------------
+// Callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid hipMalloc) have no
+// way to bring the hub kernels' partial-row workspace along; this variant keeps it in a file-scope device array.
+// Every GPU the library runs on holds its own copy of the array, at its own address, until the process ends.
+namespace disco {
+static __device__ __align__(256) unsigned char scratch[DISCO_NOALLOC_SCRATCH_BYTES];
+
+constexpr int kMaxDevices = 64;
+static void* g_scratch_ptr[kMaxDevices];   // per device: address of that device's copy of `scratch` (nullptr = not looked up)
+
+// Device address of this device's scratch array.  In host code the name `scratch` is only a stand-in for the
+// symbol, never an address: it is resolved ONCE per device with that device current, and everything afterwards
+// (kernel arguments) uses the returned pointer.
+static int scratch_for_current_device(void** out) {
+  int dev = -1;
+  DISCO_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return DISCO_EUNSUPPORTED;
+  void* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!p) {
+    DISCO_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return DISCO_EHIP;
+    __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);   // racing first calls resolve the same address
+  }
+  *out = p;
+  return DISCO_OK;
+}
+}  // namespace disco
+
+extern "C" int disco_spmm_csr_f32_noalloc(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                                          const float* x, int64_t ldx, float* y, int64_t ldy, int64_t F, int reduce,
+                                          const void* sched_ws, const disco_schedule_info* info, void* stream) {
+  size_t need = disco_spmm_workspace_bytes(info, F);
+  if (need > (size_t)DISCO_NOALLOC_SCRATCH_BYTES) return DISCO_ESCRATCH;
+  void* ws = nullptr;
+  if (need) {
+    int rc = scratch_for_current_device(&ws);
+    if (rc != DISCO_OK) return rc;
+  }
+  // Same kernels as disco_spmm_csr_f32.  Nothing in the scratch has to start at zero: every piece writes its whole
+  // partial row before k_hub_combine reads it, so the previous call's contents are simply overwritten.
+  return disco_spmm_csr_f32(rowptr, col, val, n_rows, x, ldx, y, ldy, F, reduce, sched_ws, info, ws, need, stream);
+}
+
 extern "C" int disco_khop_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n, int K,
                                   const float* x, int64_t ldx, float* y, int64_t ldy, float* tmp0, float* tmp1,
                                   int64_t ldt, int64_t F, int n_col_slices, const void* sched_ws,

@@ -33,7 +33,8 @@ enum disco_status {
   DISCO_EINVAL = -1,       /* bad argument (null pointer, negative size, misaligned ld) */
   DISCO_EUNSUPPORTED = -2, /* shape outside what the kernels are instantiated for */
   DISCO_EWORKSPACE = -3,   /* workspace too small */
-  DISCO_EHIP = -4          /* a HIP runtime call failed; see disco_last_hip_error() */
+  DISCO_EHIP = -4,         /* a HIP runtime call failed; see disco_last_hip_error() */
+  DISCO_ESCRATCH = -5      /* problem needs more than the built-in scratch of the allocation-free entry point */
 };
 
 enum disco_reduce {
@@ -113,13 +114,32 @@ int disco_sweep_build(const int64_t* rowptr, const int32_t* col, const void* sch
  * `sched_ws`/`info` may be NULL: rows are then walked in natural order and no row is split.
  * x rows are addressed by col[], so x needs >= max(col)+1 rows; x and y must not alias.
  * Deterministic: no atomics; per row the entries are accumulated in CSR order (hub rows: per
- * group in CSR order, groups and pieces combined in a fixed order). */
+ * group in CSR order, groups and pieces combined in a fixed order).
+ * Only columns [0, F) of y are written (a partial last vector is stored element by element), so y may be a
+ * column view of a wider matrix; columns [F, ldx) of x may be READ when ldx allows wider loads. */
 size_t disco_spmm_workspace_bytes(const disco_schedule_info* info_host, int64_t F);
 int disco_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                        int64_t n_rows, const float* x, int64_t ldx, float* y, int64_t ldy,
                        int64_t F, int reduce, const void* sched_ws,
                        const disco_schedule_info* info_host, void* spmm_ws, size_t spmm_ws_bytes,
                        void* stream);
+
+/* Allocation-free variant of disco_spmm_csr_f32.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc -- and
+ * therefore cannot bring the hub kernels' partial-row workspace (`spmm_ws`).  That workspace lives in a file-scope
+ * device array inside the library instead: DISCO_NOALLOC_SCRATCH_BYTES (16 MiB) per GPU the library runs on, held
+ * until the process ends.  Same arguments as disco_spmm_csr_f32 minus the workspace, same kernels, same bits.
+ *   - returns DISCO_ESCRATCH when disco_spmm_workspace_bytes(info_host, F) exceeds DISCO_NOALLOC_SCRATCH_BYTES
+ *     (n_hub_partials * roundup(F, 4) * 4 bytes; e.g. 6898 partial rows at F = 602) -- nothing is launched then;
+ *   - calls no hipMalloc / hipFree / allocating routine.  The first call on each device resolves the array's
+ *     device address (hipGetSymbolAddress): make that call once outside any capture;
+ *   - all calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams) race on the
+ *     hub rows' partial sums.  Calls on one stream, or on different GPUs, are safe. */
+#define DISCO_NOALLOC_SCRATCH_BYTES (16u << 20)
+int disco_spmm_csr_f32_noalloc(const int64_t* rowptr, const int32_t* col, const float* val,
+                               int64_t n_rows, const float* x, int64_t ldx, float* y, int64_t ldy,
+                               int64_t F, int reduce, const void* sched_ws,
+                               const disco_schedule_info* info_host, void* stream);
 
 /* ---- K-hop propagation ------------------------------------------------------------------
  * y = A^K x for a square CSR A: `for k in range(K): x = propagate(adj_t, x=x)`
