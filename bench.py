@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- K-hop GCN-normalised SpMM throughput on MI355X (BASELINE.json metric).
 
-One "step" = one K=2 propagation  Y = Â^2 X  over the whole graph (one pass of the hot path over one
-batch of synthetic input).  N=1: the Reddit-shaped configuration (BASELINE.json configs[1]:
-233k nodes, 114M edges, F=602).  N>1: the graph is 1-D row-partitioned, every rank owns a
-Reddit-shaped row block of an N-times larger graph (weak scaling) and halo feature rows are exchanged
-per hop by RCCL all-to-all over xGMI, overlapped with the interior-block SpMM.
+One "step" = one K=2 propagation  Y = A^2 X  over the whole graph (one pass of the hot path over one batch of
+synthetic input).
 
-Prints ONE JSON line on rank 0 (contract in the task statement): value = edges*feat/s of the whole
-job, plus `roofline` (dominant kernel, live HIP-event timing) and `cpu_baseline` (the oracle's OpenMP
-C port on a bounded sample, N=1 only).
+N=1   the Reddit-shaped configuration (BASELINE.json configs[1]: 233k nodes, 114.6 M edges, F=602).
+N>1   ONE global graph, 1-D row-partitioned (disco_amd/dist.py): every rank generates exactly the entries of
+      its own rows of the global graph (drawn over the GLOBAL id range), halo feature rows are exchanged per hop
+      by RCCL (all-gather of the X shards or all-to-all of the needed rows, chosen from the halo that RESULTS)
+      and overlapped with the interior-block SpMM.  Headline = weak scaling: a graph of N x 233k nodes and
+      N x 114.6 M edges with the same mean degree (every rank owns a Reddit-sized row block).
+      With WORLD_SIZE unset, `--gpus N` starts the N ranks itself (before any GPU call).
+
+Besides the headline the line carries `extra_workloads`: ogbn-products-shaped strong scaling (configs[2]: the
+SAME 2.45 M-node graph over N ranks), the papers100M-shaped graph at N = 8 (configs[4]), and the community
+variants of the generators (graphgen.py) -- see DESIGN.md section 4.
+
+Prints the JSON line on rank 0 (contract in the task statement): value = edges*feat/s of the whole job, plus
+`roofline` (dominant kernel, live HIP-event timing) and `cpu_baseline` (N=1 only: the oracle's OpenMP C port and
+BASELINE.md's two torch forms, on a bounded sample).  When extras are run the headline-only line is printed
+first and the complete line last, so that a failure inside an extra cannot lose the headline.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,234 +45,392 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="reddit", choices=["reddit", "arxiv", "products", "papers100M-shard"])
+    ap.add_argument("--workload", default="reddit", choices=["reddit", "arxiv", "products", "papers100M", "papers100M-shard"])
+    ap.add_argument("--graph", default="config", choices=["config", "community", "community-scrambled"],
+                    help="generator variant (graphgen.py): locality-free configuration model [headline], LFR-style "
+                         "communities in partitioner order, or the same behind a random relabelling (N = 1 only)")
+    ap.add_argument("--order", default="auto", choices=["auto", "degree", "locality"],
+                    help="row schedule: degree-binned, or grouped by the device-side locality pass first")
     ap.add_argument("--hops", type=int, default=2)
-    ap.add_argument("--slices", type=int, default=int(os.environ.get("DISCO_BENCH_SLICES", "0")),
-                    help="column slices per K-hop (0 = automatic: keep each slice's X under ~190 MB)")
     ap.add_argument("--ld-pad", type=int, default=32, help="pad the feature leading dimension to this many floats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0)
-    ap.add_argument("--natural-order", action="store_true", help="keep natural row order (hub split only)")
     ap.add_argument("--hub-threshold", type=int, default=0)
     ap.add_argument("--hub-piece", type=int, default=0)
     ap.add_argument("--skew", type=float, default=None)
     ap.add_argument("--sweep", default="auto", choices=["auto", "on", "off"],
                     help="L2-blocked windowed launches (auto: when the graph re-uses source rows enough)")
-    ap.add_argument("--halo-frac", type=float, default=0.25,
-                    help="N > 1: share of every rank's entries whose column belongs to another rank (reported in config)")
-    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; reported in config)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "need", "dense"], help="N > 1: halo exchange")
+    ap.add_argument("--extras", default="auto", choices=["auto", "none", "all"],
+                    help="extra workloads in the line (auto: products strong scaling, community variants, papers100M at N=8)")
+    ap.add_argument("--extras-budget-s", type=float, default=420.0, help="skip the remaining extras after this many seconds")
+    ap.add_argument("--tune", default="", help="comma-separated key=value pairs for disco_set_tuning (experiments)")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workloads (debug only; reported in config)")
     return ap.parse_args()
 
 
-def auto_slices(n_rows_x: int, F: int) -> int:
-    """Column slices per hop.  Slicing X so that one slice fits the 256 MiB Infinity Cache does not pay: a gather
-    that misses L2 costs the same whether MALL or HBM serves it, while every slice re-reads
-    (col, val) and narrows the lane groups -- products 8.4 -> 7.0 ms, papers100M shard 36.6 -> 26.7 ms per step
-    with one slice (profiles/r1/other_workloads.log)."""
-    return 1
-
-
-def b_min_bytes(nnz: int, n_rows: int, n_x_rows: int, F: int) -> float:
-    """every CSR entry read once (int32 col + f32 val), rowptr once (4 B as
-    nnz < 2^31), X read once, Y written once."""
-    return nnz * 8.0 + (n_rows + 1) * 4.0 + (n_x_rows + n_rows) * F * 4.0
-
-
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    # DISCO_DIST_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks share cards,
-    # halo rows staged through host memory); the driver's runs use RCCL, one rank per GPU.
+# ---- launcher ---------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) before anything touches the GPU."""
+    n = args.gpus
     backend = os.environ.get("DISCO_DIST_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    have = torch.cuda.device_count()          # does not initialise the GPU
+    if backend == "nccl" and have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible (set DISCO_DIST_BACKEND=gloo to rehearse "
+              f"with ranks sharing a card)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
-    from disco_amd import SparseTensor, _lib, graphgen, utils
-    lib = _lib.load()
+# ---- byte models (SURVEY.md section 8d) ----------------------------------------------------------------------
+def b_min_bytes(nnz: int, n_rows: int, F: int) -> float:
+    """Every CSR entry read once (int32 col + f32 val), rowptr once (4 B as nnz < 2^31), X read once, Y written once."""
+    return nnz * 8.0 + (n_rows + 1) * 4.0 + 2.0 * n_rows * F * 4.0
 
-    name = args.workload
-    spec = graphgen.SPECS["papers100M" if name == "papers100M-shard" else name]
-    n_local = spec.n_nodes if name != "papers100M-shard" else spec.n_nodes // 8
-    nnz_target = spec.nnz if name != "papers100M-shard" else spec.nnz // 8
+
+def b_gather_bytes(nnz: int, n_rows: int, F: int) -> float:
+    return nnz * 8.0 + (n_rows + 1) * 4.0 + nnz * F * 4.0 + n_rows * F * 4.0
+
+
+class Ctx:
+    def __init__(self, args):
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = os.environ.get("DISCO_DIST_BACKEND", "nccl")
+        idx = self.local_rank if self.backend == "nccl" else self.local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(idx)
+        self.dev = torch.device("cuda", idx)
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def max_over_ranks(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        import torch.distributed as dist
+        t = torch.tensor([v], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, step, warmup: int, steps: int) -> float:
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(warmup):
+            step(False)
+        torch.cuda.synchronize()
+        self.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        torch.cuda.synchronize()
+        self.barrier()
+        torch.cuda.synchronize()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+
+def graph_params(name: str, args, world: int):
+    """(spec, n_global, nnz_global, scaling) of a workload at this world size."""
+    from disco_amd import graphgen
+    shard = name == "papers100M-shard"
+    spec = graphgen.SPECS["papers100M" if shard else name]
+    n, nnz = spec.n_nodes, spec.nnz
+    if shard:                     # single-GPU stand-in: a square graph of 1/8 the size (r1 workload, kept for comparison)
+        n, nnz = n // 8, nnz // 8
     if args.scale != 1.0:
-        n_local = int(n_local * args.scale)
-        nnz_target = int(nnz_target * args.scale * args.scale) if name == "reddit" else int(nnz_target * args.scale)
+        n = int(n * args.scale)
+        nnz = int(nnz * args.scale * args.scale) if name == "reddit" else int(nnz * args.scale)
+    if name == "reddit" and world > 1:
+        return spec, n * world, nnz * world, "weak"
+    return spec, n, nnz, ("weak" if world == 1 else "strong")
+
+
+def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu: bool = False):
+    """Build one workload, time it, return the result dict (collective: every rank calls it)."""
+    from disco_amd import SparseTensor, _lib, graphgen, utils
+    args, dev, world, rank = ctx.args, ctx.dev, ctx.world, ctx.rank
+    lib = _lib.load()
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        _lib.check(lib.disco_set_tuning(k.encode(), int(v)), f"disco_set_tuning({k})")
+    spec, n_global, nnz_target, scaling = graph_params(name, args, world)
     F, K = spec.feat, args.hops
     skew = spec.skew if args.skew is None else args.skew
     ld = (F + args.ld_pad - 1) // args.ld_pad * args.ld_pad
-
+    comm, mu = (graphgen.COMMUNITY_SIZE, graphgen.COMMUNITY_MU) if graph.startswith("community") else (0, 1.0)
+    events = []
     t_setup = time.time()
+    cfg = {"K": K, "F": F, "ld": ld, "skew": skew, "scale": args.scale,
+           "graph": {"config": "configuration model, no locality",
+                     "community": f"LFR-style communities of {comm} nodes, mixing mu={mu}, partitioner order",
+                     "community-scrambled": f"LFR-style communities of {comm} nodes, mixing mu={mu}, ids scrambled"}[graph]}
     if world == 1:
-        # ---- single GPU: whole graph ---------------------------------------------------------------
-        row, col = graphgen.powerlaw_edges(n_local, nnz_target, skew, spec.seed, device=dev, symmetric=spec.symmetric)
-        adj = SparseTensor(row=row, col=col, value=None, sparse_sizes=(n_local, n_local), is_sorted=True)
+        row, col = graphgen.powerlaw_edges(n_global, nnz_target, skew, spec.seed, device=dev, comm_size=comm, mu=mu,
+                                           scramble=graph.endswith("scrambled"))
+        adj = SparseTensor(row=row, col=col, value=None, sparse_sizes=(n_global, n_global), is_sorted=True)
         del row, col
         if spec.norm == "normalize_adj":
             adj = utils.normalize_adj_csr(adj)      # utils.py:406-435 semantics, HIP kernels
         else:
             r, c, _ = adj.coo()                     # utils.gcn_norm(add_self_loops=False), _Sampled.py:491
-            _, w = utils.gcn_norm(torch.stack([r, c]), None, n_local, add_self_loops=False)
+            _, w = utils.gcn_norm(torch.stack([r, c]), None, n_global, add_self_loops=False)
             adj = adj.set_value(w)
             del r, c
-        nnz = adj.nnz()
+        n_local, nnz, nnz_global = n_global, adj.nnz(), adj.nnz()
         x = graphgen.features(n_local, F, spec.seed, device=dev, ld=ld)
-        y = torch.empty((n_local, ld), dtype=torch.float32, device=dev)[:, :F]
-        tmp = torch.empty((n_local, ld), dtype=torch.float32, device=dev)[:, :F]
-        n_slices = args.slices if args.slices > 0 else auto_slices(n_local, F)
-        thr = -args.hub_threshold if args.natural_order and args.hub_threshold else (-2048 if args.natural_order else args.hub_threshold)
-        ws, info = adj.schedule(thr, args.hub_piece, feat=F, sweep={"auto": None, "on": True, "off": False}[args.sweep])
-        swept = bool(info.sweep_ws) and int(info.sweep_windows) > 0
-        if swept:
-            n_slices = 1      # the library cuts the columns into its own blocks (one C-ABI call per hop)
-        sws_bytes = lib.disco_spmm_workspace_bytes(info, F)
-        sws = torch.empty(max(int(sws_bytes), 16), dtype=torch.uint8, device=dev)
-        per = (F + n_slices - 1) // n_slices
-        per = (per + 31) // 32 * 32
-        col_slices = [(c0, min(per, F - c0)) for c0 in range(0, F, per)]
+        bufs = [torch.empty((n_local, ld), dtype=torch.float32, device=dev)[:, :F] for _ in range(min(K, 3))]
+        order = args.order
+        if order == "auto":
+            order = "degree"
+        if order == "locality":
+            adj.set_row_groups(adj.locality_groups())
+        ws, info = adj.schedule(args.hub_threshold, args.hub_piece, feat=F, sweep={"auto": None, "on": True, "off": False}[args.sweep])
+        sws_bytes = int(lib.disco_spmm_workspace_bytes(info, F))
+        sws = torch.empty(max(sws_bytes, 16), dtype=torch.uint8, device=dev)
         stream = _lib.current_stream(dev)
-        events = []
 
         def step(record: bool):
-            # same work as disco_khop_csr_f32, issued hop by hop so that each launch can be timed
-            for c0, f in col_slices:
-                src = x
-                for k in range(K):
-                    dst = y if k == K - 1 else tmp
-                    if record:
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                    _lib.check(lib.disco_spmm_csr_f32(adj._rowptr.data_ptr(), adj._col32.data_ptr(), adj._value.data_ptr(),
-                                                      n_local, src.data_ptr() + 4 * c0, src.stride(0), dst.data_ptr() + 4 * c0,
-                                                      dst.stride(0), f, 0, ws.data_ptr(), info, sws.data_ptr(), sws.numel(),
-                                                      stream), "disco_spmm_csr_f32")
-                    if record:
-                        e1.record()
-                        events.append((e0, e1, f))
-                    src = dst
+            # the work of disco_khop_csr_f32, issued hop by hop so that each hop can be timed
+            src = x
+            for k in range(K):
+                dst = bufs[0] if k == K - 1 else bufs[1 + (k & 1)]
+                if record:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                _lib.check(lib.disco_spmm_csr_f32(adj._rowptr.data_ptr(), adj._col32.data_ptr(), adj._value.data_ptr(),
+                                                  n_local, src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), F, 0,
+                                                  ws.data_ptr(), info, sws.data_ptr(), sws.numel(), stream), "disco_spmm_csr_f32")
+                if record:
+                    e1.record()
+                    events.append((e0, e1))
+                src = dst
 
-        units_per_step = float(K) * nnz * F
-        algo_bytes = lambda f: b_min_bytes(nnz, n_local, n_local, f)  # noqa: E731
-        parallelism = "single"
-        halo_info = None
+        windows = int(info.sweep_windows) if info.sweep_ws else 0
+        cfg.update({"parallelism": "single", "row_order": order, "l2_windows": windows,
+                    "schedule": {"hub_rows": int(info.n_hub_rows), "hub_pieces": int(info.n_hub_pieces),
+                                 "max_row_nnz": int(info.max_row_nnz)}})
+        kernel = (f"k_spmm_rows_win: one timed call = one hop = {windows} window launches x column blocks of <= 128 floats"
+                  if windows else "k_spmm_rows (+ k_spmm_hub, same C-ABI call)")
     else:
         from disco_amd import dist as ddist
-        part = ddist.build_weak_scaling_partition(spec, n_local, nnz_target, skew, world, rank, dev, ld, halo_frac=args.halo_frac)
-        nnz = part.nnz_local
-        n_slices = 1
-        events = []
+        g = ddist.build_partitioned_graph(n_global, nnz_target, F, skew, spec.seed, spec.norm, world, rank, dev, ld,
+                                          comm_size=comm, mu=mu, exchange=args.exchange, K=K)
+        n_local, nnz, nnz_global = g.part.n_local, g.nnz_local, g.nnz_global
+        g.part.adj_int.schedule(feat=F)
+        if g.part.adj_halo.nnz():
+            g.part.adj_halo.schedule(feat=F)
+        ev3 = []
 
         def step(record: bool):
-            part.khop(K, events if record else None)
+            g.khop(K, ev3 if record else None)
+            if record:
+                events.extend((a, b) for a, b, _ in ev3)
+                ev3.clear()
 
-        units_per_step = float(K) * part.nnz_global * F
-        algo_bytes = lambda f: b_min_bytes(part.nnz_local, n_local, part.n_x_rows, f)  # noqa: E731
-        parallelism = f"row-partition x{world}, halo all-to-all"
-        halo_info = part.describe()
-        info = part.info_main
+        cfg.update({"parallelism": f"1-D row partition x{world} of one global graph", "halo": g.describe(),
+                    "rows_global": n_global})
+        kernel = "k_spmm_rows on the interior block + halo block (y += A_halo x_recv), exchange overlapped"
+        adj, x = None, None
     torch.cuda.synchronize()
+    ctx.barrier()
     t_setup = time.time() - t_setup
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- roofline of the dominant kernel (k_spmm_rows), live HIP-event timing ------------------------
-    durs_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
-    tot_bytes = sum(algo_bytes(f) for _, _, f in events)
-    avg_ms = sum(durs_ms) / max(len(durs_ms), 1)
-    achieved = tot_bytes / (sum(durs_ms) * 1e-3) / 1e9 if durs_ms else 0.0
-    swept_now = world == 1 and bool(info.sweep_ws) and int(info.sweep_windows) > 0
-    kernel_name = ("k_spmm_rows_win: one timed call = one hop = %d window launches x column blocks of <= 128 floats"
-                   % int(info.sweep_windows)) if swept_now else "k_spmm_rows (+ k_spmm_hub, same C-ABI call)"
-    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernel": kernel_name, "launches_per_step": len(events) // max(args.steps, 1),
-                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": round(tot_bytes / max(len(events), 1)),
-                "gather_model_GBs": round((sum((nnz * 8.0 + nnz * f * 4.0 + n_local * f * 4.0) for _, _, f in events))
-                                          / (sum(durs_ms) * 1e-3) / 1e9, 1) if durs_ms else 0.0}
-
-    # HBM/fabric bytes per launch from the PMC passes committed under profiles/ (same command, same config);
-    # bench.py cannot read hardware counters itself.
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")) as fh:
-            pmc = json.load(fh)
-        key = "reddit_K2_windowed" if swept_now else "reddit_K2_slices3"
-        if world == 1 and name == "reddit" and args.scale == 1.0 and (swept_now or n_slices == 3) and key in pmc:
-            roofline["traffic"] = round(pmc[key]["traffic_bytes_per_launch"])
-            roofline["traffic_source"] = "profiles/r1/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 read correction)"
-    except (OSError, KeyError, ValueError):
-        pass
-
-    value = units_per_step * args.steps / elapsed
-    out = {
-        "metric": "K-hop SpMM edges*feat/s", "value": value, "unit": "edges*feat/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{spec.name} K={K} GCN-normalised propagation, N={n_local}{'/rank' if world > 1 else ''}, "
-                               f"nnz={nnz}{'/rank' if world > 1 else ''} (incl. self-loops), F={F}",
-                   "K": K, "F": F, "nnz_per_rank": nnz, "rows_per_rank": n_local, "col_slices": n_slices, "ld": ld,
-                   "l2_windows": int(info.sweep_windows) if info.sweep_ws else 0,
-                   "skew": skew, "parallelism": parallelism, "scale": args.scale,
-                   "schedule": {"hub_rows": int(info.n_hub_rows), "hub_pieces": int(info.n_hub_pieces),
-                                "max_row_nnz": int(info.max_row_nnz)},
-                   "setup_s": round(t_setup, 1)},
-        "roofline": roofline,
+    elapsed = ctx.timed(step, warmup, steps)
+    durs_ms = [a.elapsed_time(b) for a, b in events]
+    hop_ms = sum(durs_ms) / max(len(durs_ms), 1)
+    algo = b_min_bytes(nnz, n_local, F)                      # this rank's share per hop
+    achieved = algo / (hop_ms * 1e-3) / 1e9 if durs_ms else 0.0
+    value = float(K) * nnz_global * F * steps / elapsed
+    cfg.update({"nnz_per_rank": nnz, "rows_per_rank": n_local, "nnz_global": nnz_global, "setup_s": round(t_setup, 1)})
+    res = {
+        "value": value, "ms_per_step": elapsed / steps * 1e3, "scaling": scaling, "n_gpus": world,
+        "workload": f"{spec.name}{' (1/8-size square stand-in)' if name == 'papers100M-shard' else ''} K={K} GCN-normalised "
+                    f"propagation, N={n_global}, nnz={nnz_global} (incl. self-loops), F={F}",
+        "config": cfg,
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel,
+                     "launches_per_step": len(events) // max(steps, 1), "avg_launch_ms": round(hop_ms, 4),
+                     "algorithmic_bytes_per_launch": round(algo),
+                     "gather_model_GBs": round(b_gather_bytes(nnz, n_local, F) / (hop_ms * 1e-3) / 1e9, 1) if durs_ms else 0.0},
     }
-    if halo_info:
-        out["config"]["halo"] = halo_info
+    # HBM / fabric bytes per hop from the PMC passes committed under profiles/ for exactly this configuration
+    # (bench.py cannot read hardware counters itself); null when no matching measurement exists.
+    if world == 1 and args.scale == 1.0:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            key = f"{name}_{graph}_{cfg['row_order']}_windows{cfg['l2_windows']}"
+            if key in pmc:
+                res["roofline"]["traffic"] = round(pmc[key]["traffic_bytes_per_hop"])
+                res["roofline"]["traffic_source"] = f"profiles/r2/pmc_traffic.json[{key}]"
+        except (OSError, KeyError, ValueError):
+            pass
+    if want_cpu and world == 1:
+        res["cpu_baseline"] = cpu_baselines(adj, x, F, args)
+    return res
 
-    # ---- CPU baseline: the oracle's OpenMP C port on a bounded sample (rank 0, N=1 only) --------------
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import c_oracle
-        rows = args.cpu_sample_rows or max(256, min(n_local, int(1.0e10 / max(1.0, nnz / n_local * F))))
-        rows = min(rows, n_local)
-        rp = adj._rowptr[: rows + 1].cpu().numpy()
-        e_end = int(rp[-1])
-        cs = adj._col32[:e_end].cpu().numpy().astype("int64")
-        vs = adj._value[:e_end].cpu().numpy()
-        xh = x.cpu().numpy()
-        c_oracle.spmm_csr_f32(rp[:65], cs, vs, xh)  # touch / warm
-        tc = time.perf_counter()
-        reps = 2
-        for _ in range(reps):
-            c_oracle.spmm_csr_f32(rp, cs, vs, xh, "sum")
-        tc = time.perf_counter() - tc
-        out["cpu_baseline"] = {"value": e_end * F * reps / tc, "unit": "edges*feat/s", "cores": c_oracle.num_threads(),
-                               "kind": "port",
-                               "sample": f"rows [0,{rows}) of the same normalised CSR ({e_end} entries), {reps} SpMM passes at F={F}, "
-                                         f"oracle/spmm_ref.c (OpenMP), {tc:.1f} s"}
-    if rank == 0:
-        print(json.dumps(out))
+
+def cpu_baselines(adj, x, F, args):
+    """CPU figures timed on this box's host cores, each on a bounded sample of the SAME normalised CSR (rows [0, R)):
+      port      the oracle's OpenMP C restatement of torch_sparse's CPU spmm_sum (oracle/spmm_ref.c)   [headline object]
+      torch_csr BASELINE.md section 2 "CSR form":     torch.sparse_csr @ X
+      scatter   BASELINE.md section 2 "scatter form": index_select -> mul -> index_add_  (PyG's non-fused route)"""
+    from oracle import c_oracle
+    n_local, nnz = adj.size(0), adj.nnz()
+    rows = args.cpu_sample_rows or max(256, min(n_local, int(1.0e10 / max(1.0, nnz / n_local * F))))
+    rows = min(rows, n_local)
+    rp_t = adj._rowptr[: rows + 1].cpu()
+    e_end = int(rp_t[-1])
+    col_t = adj._col32[:e_end].cpu().to(torch.int64)
+    val_t = adj._value[:e_end].cpu()
+    x_t = x.cpu().contiguous()
+    rp, cs, vs, xh = rp_t.numpy(), col_t.numpy(), val_t.numpy(), x_t.numpy()
+    c_oracle.spmm_csr_f32(rp[:65], cs, vs, xh)  # touch / warm
+    reps = 2
+    tc = time.perf_counter()
+    for _ in range(reps):
+        c_oracle.spmm_csr_f32(rp, cs, vs, xh, "sum")
+    tc = time.perf_counter() - tc
+    sample = f"rows [0,{rows}) of the same normalised CSR ({e_end} entries) at F={F}"
+    out = {"value": e_end * F * reps / tc, "unit": "edges*feat/s", "cores": c_oracle.num_threads(), "kind": "port",
+           "sample": f"{sample}, {reps} SpMM passes, oracle/spmm_ref.c (OpenMP), {tc:.1f} s"}
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    # bounded sub-samples for the two torch forms (they are 1-2 orders of magnitude slower than the port)
+    forms = []
+    try:
+        r2 = max(64, rows // 8)
+        e2 = int(rp_t[r2])
+        a = torch.sparse_csr_tensor(rp_t[: r2 + 1], col_t[:e2], val_t[:e2], (r2, x_t.shape[0]))
+        a @ x_t[:, :8]
+        t0 = time.perf_counter()
+        a @ x_t
+        t1 = time.perf_counter() - t0
+        forms.append({"form": "torch.sparse_csr @ X (BASELINE.md 2, CSR form)", "kind": "port", "value": e2 * F / t1,
+                      "unit": "edges*feat/s", "cores": threads, "sample": f"rows [0,{r2}) ({e2} entries), 1 pass, {t1:.1f} s"})
+        r3 = max(64, rows // 32)
+        e3 = int(rp_t[r3])
+        rowid = torch.repeat_interleave(torch.arange(r3), rp_t[1: r3 + 1] - rp_t[:r3])
+        t0 = time.perf_counter()
+        msg = x_t.index_select(0, col_t[:e3])
+        msg.mul_(val_t[:e3, None])
+        torch.zeros(r3, F).index_add_(0, rowid, msg)
+        t2 = time.perf_counter() - t0
+        forms.append({"form": "index_select -> mul -> index_add_ (BASELINE.md 2, scatter form)", "kind": "port",
+                      "value": e3 * F / t2, "unit": "edges*feat/s", "cores": threads,
+                      "sample": f"rows [0,{r3}) ({e3} entries), 1 pass, {t2:.1f} s"})
+    except Exception as exc:  # noqa: BLE001  (a baseline that cannot run must not lose the GPU result)
+        forms.append({"error": repr(exc)})
+    out["torch_forms"] = forms
+    return out
+
+
+def run_scorer(ctx: Ctx, steps: int, warmup: int):
+    """configs[3]: PGE_Edge over all pairs of 25 000 condensed nodes (MFMA-bound); step = one edge_construction."""
+    from disco_amd.models.parametrized_adj_lp import PGE_Edge
+    args, dev = ctx.args, ctx.dev
+    n, d, H = max(256, int(25000 * args.scale)), 128, 256
+    torch.manual_seed(20250226)
+    pge = PGE_Edge(nfeat=2 * d, nhid=H, device=dev).to(dev).eval()
+    Z = torch.randn(n, 2 * d, device=dev)
+    events = []
+
+    def step(record: bool):
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        pge.edge_construction(Z, 0.99, "transductive")
+        if record:
+            e1.record()
+            events.append((e0, e1))
+
+    elapsed = ctx.timed(step, warmup, steps)
+    ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
+    flops = 2.0 * n * n * (H * H + H) + 2.0 * n * 2 * (2 * d) * H
+    peak = 157.3
+    return {"workload": f"PGE_Edge pair scoring + symmetrise/threshold/COO, n={n}, nfeat={2 * d}, hidden={H}", "n_gpus": 1,
+            "value": n * n * steps / elapsed, "unit": "pairs/s", "ms_per_step": elapsed / steps * 1e3,
+            "roofline": {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "traffic": None,
+                         "kernel": "k_scorer_pairs<256> (v_mfma_f32_32x32x2_f32), whole edge_construction timed"}}
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    ctx = Ctx(args)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(ctx.backend, **({"device_id": ctx.dev} if ctx.backend == "nccl" else {}))
+    t_start = time.time()
+
+    head = run_spmm(ctx, args.workload, args.graph, args.steps, args.warmup, want_cpu=not args.no_cpu_baseline)
+    out = {
+        "metric": "K-hop SpMM edges*feat/s", "value": head["value"], "unit": "edges*feat/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+        "scaling": head["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": dict(head["config"], workload=head["workload"]), "roofline": head["roofline"],
+    }
+    if "cpu_baseline" in head:
+        out["cpu_baseline"] = head["cpu_baseline"]
+
+    extras = []
+    if args.extras != "none" and args.workload == "reddit" and args.graph == "config":
+        plan = [("products", "config"), ("products", "community")]
+        if world > 1:
+            plan = [("reddit", "community")] + plan
+        else:
+            plan += [("scorer", "")]
+        if world == 8 or args.extras == "all":
+            plan += [("papers100M", "community"), ("papers100M", "config")] if world > 1 else []
+        if rank0(ctx):
+            print(json.dumps(out), flush=True)      # headline first: nothing below can lose it
+        for name, graph in plan:
+            go = 1 if time.time() - t_start < args.extras_budget_s else 0
+            if world > 1:       # rank 0 decides for everybody
+                flag = torch.tensor([go], dtype=torch.int64, device=ctx.dev if ctx.backend == "nccl" else "cpu")
+                dist.broadcast(flag, src=0)
+                go = int(flag.item())
+            if not go:
+                extras.append({"workload": f"{name} ({graph})", "skipped": "time budget"})
+                continue
+            torch.cuda.empty_cache()
+            if name == "scorer":
+                r = run_scorer(ctx, max(1, min(args.steps, 3)), 1)
+            else:
+                r = run_spmm(ctx, name, graph, args.steps, args.warmup)
+                r["unit"] = "edges*feat/s"
+            extras.append(r)
+        out["extra_workloads"] = extras
+    if rank0(ctx):
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def rank0(ctx: Ctx) -> bool:
+    return ctx.rank == 0
 
 
 if __name__ == "__main__":

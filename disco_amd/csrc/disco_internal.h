@@ -20,6 +20,7 @@ struct Tuning {
   int psync_pct = 0;  // sweep_mode 3: share of a sync group's waves a wave waits for (0 = 100)
   int psync_polls = 0;  // sweep_mode 3: polls before a wave gives up waiting (0 = 256)
   int addr24 = 1;     // 0 = always 64-bit gather addressing
+  int xcd_map = 0;    // 1 = the workgroups of one XCD walk one contiguous eighth of the row order (k_spmm_rows)
 };
 
 Tuning& tuning();

@@ -229,13 +229,18 @@ __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ r
                                                    const float* __restrict__ val, const float* __restrict__ x,
                                                    int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
                                                    const uint32_t* __restrict__ perm, int64_t first, int64_t count,
-                                                   int flags, int fcols) {
+                                                   int flags, int fcols, int64_t xcd_chunk) {
   typedef typename Vec<VEC>::type V;
   constexpr int RPW = 64 / G;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int gl = lane % G;
-  int64_t grp = ((int64_t)blockIdx.x * 4 + wave) * RPW + lane / G;
+  // XCD-aware block order (speed only): workgroups are dealt round-robin over the 8 XCDs, so workgroup b and
+  // b + 8 share an L2.  With xcd_chunk > 0 the workgroups of one XCD walk ONE contiguous eighth of the row order
+  // (consecutive rows of a locality-grouped order share neighbours: their gathers hit that XCD's L2).
+  int64_t bid = blockIdx.x;
+  if (xcd_chunk > 0) bid = (int64_t)(blockIdx.x & 7) * xcd_chunk + (blockIdx.x >> 3);
+  int64_t grp = (bid * 4 + wave) * RPW + lane / G;
   if (grp >= count) return;
   int64_t row = perm ? (int64_t)perm[first + grp] : first + grp;
   int64_t beg = rowptr[row], end = rowptr[row + 1];
@@ -801,9 +806,11 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
   }
   if (count > 0 && !swept) {
     int64_t blocks = (count + 4 * RPW - 1) / (4 * RPW);
+    int64_t xcd_chunk = 0;
+    if (tuning().xcd_map && blocks >= 64) { xcd_chunk = (blocks + 7) / 8; blocks = xcd_chunk * 8; }
     if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
     hipLaunchKernelGGL((k_spmm_rows<VEC, G, NV, OP, HASVAL, A24>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
-                       a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, mean, (int)a.F);
+                       a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, mean, (int)a.F, xcd_chunk);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_last_hip_error((int)e); return DISCO_EHIP; }

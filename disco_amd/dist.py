@@ -17,7 +17,7 @@ the CPU (gloo) tests can check the partition / exchange logic against the oracle
 from __future__ import annotations
 
 import os
-from dataclasses import dataclass
+from dataclasses import dataclass, field  # noqa: F401
 from typing import Callable, List, Optional
 
 import torch
@@ -64,60 +64,77 @@ class RowPartition:
     """This rank's share of a row-partitioned square adjacency.
 
     rowptr/col/val: CSR of the LOCAL rows with GLOBAL column ids; ``col_offsets`` (world+1) gives the
-    column (= row) ownership ranges.
+    column (= row) ownership ranges.  ``exchange``: "need" = all-to-all(v) of exactly the rows each peer
+    needs; "dense" = one all-gather of the X shards (blocks padded to the largest), the halo block then indexes
+    the gathered table; "auto" picks "dense" when this rank needs more than half of all remote rows anyway
+    (a graph without locality: the request lists, the index_select and the uneven all-to-all buy nothing).
+    The choice is made collectively (every rank must run the same collective).
     """
 
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], col_offsets: List[int],
-                 rank: int, world: int, group=None, spmm_fn: Optional[Callable] = None):
+                 rank: int, world: int, group=None, spmm_fn: Optional[Callable] = None, exchange: str = "auto"):
         self.rank, self.world, self.group = rank, world, group
         dev = col.device
         self.device = dev
         self.col_offsets = list(col_offsets)
         lo, hi = col_offsets[rank], col_offsets[rank + 1]
         self.n_local = rowptr.numel() - 1
+        self.n_global = col_offsets[-1]
         assert self.n_local == hi - lo, "row block must match the owned column range"
         self.nnz_local = int(col.numel())
+        col = col.to(torch.int64)
         row = torch.repeat_interleave(torch.arange(self.n_local, device=dev), rowptr[1:] - rowptr[:-1])
         interior = (col >= lo) & (col < hi)
         # interior block: local column ids
         self.adj_int = SparseTensor(row=row[interior], col=col[interior] - lo,
                                     value=None if val is None else val[interior],
                                     sparse_sizes=(self.n_local, self.n_local), is_sorted=True)
-        # halo block: columns renumbered into the receive buffer (sorted by global id => grouped by owner)
-        hcol = col[~interior]
-        need, inv = torch.unique(hcol, return_inverse=True)      # sorted global ids this rank needs
+        hrow, hcol = row[~interior], col[~interior]
+        hval = None if val is None else val[~interior]
+        del row, interior
+        need = torch.unique(hcol)                                 # sorted global ids this rank needs
         self.n_halo = int(need.numel())
-        self.adj_halo = SparseTensor(row=row[~interior], col=inv, value=None if val is None else val[~interior],
-                                     sparse_sizes=(self.n_local, max(self.n_halo, 1)), is_sorted=True)
-        bounds = torch.tensor(col_offsets, device=dev, dtype=need.dtype)
+        self.halo_nnz = int(hcol.numel())
+        if os.environ.get("DISCO_DENSE_HALO") == "1":
+            exchange = "dense"
+        if exchange == "auto":
+            vote = torch.tensor([1 if self.n_halo * 2 > self.n_global - self.n_local else 0], dtype=torch.int64,
+                                device=dev if world > 1 and dist.get_backend(group) != "gloo" else "cpu")
+            if world > 1:
+                dist.all_reduce(vote, group=group)
+            exchange = "dense" if int(vote) * 2 > world else "need"
+        self.dense = world > 1 and exchange == "dense"
+        self._spmm = spmm_fn
+        self._send_buf = self._recv_buf = self._full_buf = self._mine_buf = None
+        bounds = torch.tensor(col_offsets, device=dev, dtype=torch.int64)
+        if self.dense:
+            # halo block over the all-gathered table: shard g sits at rows [g * per, g * per + size_g)
+            self.per = max(col_offsets[g + 1] - col_offsets[g] for g in range(world))
+            owner = torch.bucketize(hcol, bounds[1:], right=True)
+            self.adj_halo = SparseTensor(row=hrow, col=owner * self.per + (hcol - bounds[owner]), value=hval,
+                                         sparse_sizes=(self.n_local, world * self.per), is_sorted=True)
+            self.send_idx = torch.empty(0, dtype=torch.int64, device=dev)
+            self.send_splits = self.recv_splits = [0] * world
+            return
+        # need-only: columns renumbered into the receive buffer (sorted by global id => grouped by owner)
+        inv = torch.searchsorted(need, hcol)
+        self.adj_halo = SparseTensor(row=hrow, col=inv, value=hval, sparse_sizes=(self.n_local, max(self.n_halo, 1)),
+                                     is_sorted=True)
         owner_start = torch.searchsorted(need, bounds)            # position of each owner's first needed row
-        self.recv_splits = [int(owner_start[g + 1] - owner_start[g]) for g in range(world)]
+        self.recv_splits = (owner_start[1:] - owner_start[:-1]).tolist()
         assert self.recv_splits[rank] == 0
         # tell every owner which of its rows we need
         send_counts = torch.zeros(world, dtype=torch.int64, device=dev)
         recv_counts = torch.tensor(self.recv_splits, dtype=torch.int64, device=dev)
         if world > 1:
             _all_to_all(send_counts, recv_counts, group=group)
-        self.send_splits = [int(v) for v in send_counts.tolist()]
+        self.send_splits = send_counts.tolist()
         want_local = need - bounds[torch.bucketize(need, bounds[1:], right=True)]  # ids local to their owner
         self.send_idx = torch.empty(sum(self.send_splits), dtype=torch.int64, device=dev)
         if world > 1:
             _all_to_all(self.send_idx, want_local.contiguous(), self.send_splits, self.recv_splits, group=group)
         if self.send_idx.numel():
             assert int(self.send_idx.max()) < self.n_local and int(self.send_idx.min()) >= 0
-        self._spmm = spmm_fn
-        self._send_buf = None
-        self._recv_buf = None
-        # Dense-halo variant (opt-in, DISCO_DENSE_HALO=1, equal row blocks only): when every peer needs (nearly)
-        # every row -- the Reddit-shaped shards: 123 remote neighbours per row -- the need-only exchange
-        # degenerates into an all-gather of X, which needs no index_select and is RCCL's best-tuned collective.
-        # The halo block then indexes the all-gathered table by GLOBAL column id.
-        sizes = {col_offsets[g + 1] - col_offsets[g] for g in range(world)}
-        self.dense = world > 1 and len(sizes) == 1 and os.environ.get("DISCO_DENSE_HALO") == "1"
-        if self.dense:
-            self.adj_halo_dense = SparseTensor(row=row[~interior], col=hcol, value=None if val is None else val[~interior],
-                                               sparse_sizes=(self.n_local, world * self.n_local), is_sorted=True)
-            self._full_buf = None
 
     # ---- one propagation -------------------------------------------------------------------------
     def _spmm_call(self, adj, x, reduce, out):
@@ -126,9 +143,13 @@ class RowPartition:
         from . import ops
         return ops.spmm_raw(adj, x, reduce, out=out)
 
+    @staticmethod
+    def _xld(F: int) -> int:
+        return (F + 3) // 4 * 4      # exchange buffers: 16-byte rows (128-bit gathers), no wider padding on the wire
+
     def _buffers(self, x: torch.Tensor):
-        ld = x.stride(0)
         F = x.shape[1]
+        ld = self._xld(F)
         if self._send_buf is None or self._send_buf.shape[1] != ld:
             self._send_buf = torch.empty((max(self.send_idx.numel(), 1), ld), dtype=x.dtype, device=x.device)
             self._recv_buf = torch.empty((max(self.n_halo, 1), ld), dtype=x.dtype, device=x.device)
@@ -142,26 +163,26 @@ class RowPartition:
         ns = self.send_idx.numel()
         if ns:
             torch.index_select(x, 0, self.send_idx, out=send[:ns])
-        ld = x.stride(0)
-        # whole padded rows travel (contiguous buffers): splits are in rows of `ld` floats
-        sflat = self._send_buf[:max(ns, 0)].reshape(-1) if ns else self._send_buf[:0].reshape(-1)
-        rflat = self._recv_buf[:self.n_halo].reshape(-1) if self.n_halo else self._recv_buf[:0].reshape(-1)
+        ld = self._send_buf.shape[1]
+        sflat = self._send_buf[:ns].reshape(-1)
+        rflat = self._recv_buf[:self.n_halo].reshape(-1)
         work = _all_to_all(rflat, sflat, [c * ld for c in self.recv_splits], [c * ld for c in self.send_splits],
                            group=self.group, async_op=True)
         return work, recv
 
     def _spmm_dense(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-        ld, F, n = x.stride(0), x.shape[1], self.n_local
+        F, n = x.shape[1], self.n_local
+        ld = self._xld(F)
         if self._full_buf is None or self._full_buf.shape[1] != ld:
-            self._full_buf = torch.empty((self.world * n, ld), dtype=x.dtype, device=x.device)
-            self._mine_buf = torch.zeros((n, ld), dtype=x.dtype, device=x.device)
-        self._mine_buf[:, :F].copy_(x)
+            self._full_buf = torch.empty((self.world * self.per, ld), dtype=x.dtype, device=x.device)
+            self._mine_buf = torch.zeros((self.per, ld), dtype=x.dtype, device=x.device)
+        self._mine_buf[:n, :F].copy_(x)
         work = _all_gather_into(self._full_buf.reshape(-1), self._mine_buf.reshape(-1), self.group, async_op=True)
         self._spmm_call(self.adj_int, x, "sum", out)              # overlaps with the all-gather
         if work is not None:
             work.wait()
-        if self.adj_halo_dense.nnz():
-            self._spmm_call(self.adj_halo_dense, self._full_buf[:, :F], "sum_acc", out)
+        if self.adj_halo.nnz():
+            self._spmm_call(self.adj_halo, self._full_buf[:, :F], "sum_acc", out)
         return out
 
     def spmm(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
@@ -176,23 +197,30 @@ class RowPartition:
             self._spmm_call(self.adj_halo, recv, "sum_acc", out)
         return out
 
+    def exchange_bytes_per_hop(self, F: int) -> int:
+        """Bytes this rank RECEIVES per hop."""
+        ld = self._xld(F)
+        if self.dense:
+            return (self.world - 1) * self.per * ld * 4
+        return self.n_halo * ld * 4
+
 
 @dataclass
-class WeakScalingShard:
+class PartitionedGraph:
+    """One rank's share of a BASELINE-shaped global graph, with its feature / output / ping-pong buffers."""
     part: RowPartition
     x: torch.Tensor
     y: torch.Tensor
-    tmp: torch.Tensor
+    tmp: List[torch.Tensor]
+    F: int
     nnz_local: int
     nnz_global: int
-    n_x_rows: int
-    info_main: object
-    halo_frac: float
+    n_global: int
 
     def khop(self, K: int, events=None):
         src = self.x
         for k in range(K):
-            dst = self.y if k == K - 1 else self.tmp
+            dst = self.y if k == K - 1 else self.tmp[k & 1]
             if events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -201,61 +229,66 @@ class WeakScalingShard:
                 e1.record()
                 events.append((e0, e1, src.shape[1]))
             src = dst
+        return self.y
 
     def describe(self):
         p = self.part
-        return {"halo_rows": p.n_halo, "send_rows": int(p.send_idx.numel()), "interior_nnz": p.adj_int.nnz(),
-                "halo_nnz": p.adj_halo.nnz(), "halo_edge_fraction": round(p.adj_halo.nnz() / max(p.nnz_local, 1), 4),
-                "exchange": "all_to_all_single (RCCL), async, overlapped with the interior SpMM"}
+        remote = self.n_global - p.n_local
+        return {"exchange": ("all_gather_into_tensor of the X shards" if p.dense else "all_to_all_single of the needed rows") +
+                            " (RCCL), async, overlapped with the interior SpMM",
+                "halo_rows_needed": p.n_halo, "remote_rows": remote,
+                "halo_row_fraction": round(p.n_halo / max(remote, 1), 4),
+                "interior_nnz": p.adj_int.nnz(), "halo_nnz": p.halo_nnz,
+                "halo_edge_fraction": round(p.halo_nnz / max(p.nnz_local, 1), 4),
+                "recv_bytes_per_hop": p.exchange_bytes_per_hop(self.F)}
 
 
-def build_weak_scaling_partition(spec, n_local: int, nnz_local: int, skew: float, world: int, rank: int, device, ld: int,
-                                 halo_frac: float = 0.25) -> WeakScalingShard:
-    """Every rank owns a `spec`-shaped row block of a world-times larger graph.  A share ``halo_frac`` of
-    each row block's entries points to columns owned by other ranks (drawn over all of them), the
-    rest stays inside the rank's own block -- the shape a locality-aware partition of a community
-    graph gives.  Normalisation: row-degree on both sides (utils.py:406-435 semantics, +I), the
-    r = deg^-1/2 vector is all-gathered once at set-up."""
+def build_partitioned_graph(n_global: int, nnz_global: int, F: int, skew: float, seed: int, norm: str, world: int, rank: int,
+                            device, ld: int, comm_size: int = 0, mu: float = 1.0, exchange: str = "auto", K: int = 2,
+                            group=None, spmm_fn: Optional[Callable] = None) -> PartitionedGraph:
+    """Rank ``rank``'s row block of a GLOBAL symmetric graph (``graphgen.partition_edges``: every rank generates
+    exactly the entries of its own rows, drawn over the global id range), normalised the way the reference
+    normalises that dataset, wrapped in a ``RowPartition``.  How many halo rows / entries result is an OUTCOME
+    of the graph and the partition (``describe()``), not an input.
+      norm = "normalize_adj": +I, r = rowsum^-1/2 in float64, one rounding  (/root/reference/utils.py:406-435)
+      norm = "gcn_norm"     : deg^-1/2 in float32, (dis[row] * 1) * dis[col]  (utils.py:242-247; the symmetric graph's
+                              column degree equals its row degree)
+    The degree vector is local under a row partition; r / dis of the remote columns needs ONE all-gather of an
+    N-vector at set-up."""
     from . import graphgen
-    n_global = n_local * world
-    lo = rank * n_local
-    seed = spec.seed + 1000 * rank
-    n_int = int(nnz_local * (1.0 - halo_frac)) if world > 1 else nnz_local
-    ri, ci = graphgen.powerlaw_edges(n_local, n_int, skew, seed, device=device, symmetric=True, add_diag=True)
-    ci = ci + lo
-    if world > 1 and halo_frac > 0:
-        rh, ch = graphgen.powerlaw_edges(n_local, nnz_local - n_int, skew, seed + 1, device=device, symmetric=False,
-                                         n_cols=n_global - n_local)
-        ch = torch.where(ch >= lo, ch + n_local, ch)              # skip the own column block
-        key = torch.unique(torch.cat([ri * n_global + ci, rh * n_global + ch]))
-        row, col = key // n_global, key % n_global
-    else:
-        row, col = ri, ci
+    row, col, offs = graphgen.partition_edges(n_global, nnz_global, skew, seed, world, rank, device, comm_size, mu,
+                                              add_diag=(norm == "normalize_adj"))
+    lo, hi = offs[rank], offs[rank + 1]
+    n_local = hi - lo
     counts = torch.bincount(row, minlength=n_local)
     rowptr = torch.zeros(n_local + 1, dtype=torch.int64, device=device)
     torch.cumsum(counts, 0, out=rowptr[1:])
-    r_local = counts.to(torch.float64).pow(-0.5)
+    wdt = torch.float64 if norm == "normalize_adj" else torch.float32
+    r_local = counts.to(wdt).pow(-0.5)
     r_local[torch.isinf(r_local)] = 0
     if world > 1:
-        r_all = torch.empty(n_global, dtype=torch.float64, device=device)
-        _all_gather_into(r_all, r_local.contiguous())
+        per = max(offs[g + 1] - offs[g] for g in range(world))
+        mine = torch.zeros(per, dtype=wdt, device=device)
+        mine[:n_local] = r_local
+        padded = torch.empty(world * per, dtype=wdt, device=device)
+        _all_gather_into(padded, mine, group)
+        r_all = torch.cat([padded[g * per: g * per + offs[g + 1] - offs[g]] for g in range(world)])
     else:
         r_all = r_local
     val = (r_local[row] * r_all[col]).to(torch.float32)
-    offs = [g * n_local for g in range(world + 1)]
-    part = RowPartition(rowptr, col, val, offs, rank, world)
-    F = spec.feat
-    x = graphgen.features(n_local, F, seed, device=device, ld=ld)
-    y = torch.empty((n_local, ld), dtype=torch.float32, device=device)[:, :F]
-    tmp = torch.empty((n_local, ld), dtype=torch.float32, device=device)[:, :F]
+    del r_all
     nnz_l = int(col.numel())
+    part = RowPartition(rowptr, col, val, offs, rank, world, group=group, exchange=exchange, spmm_fn=spmm_fn)
+    del row, col, val
+    x = graphgen.features(n_local, F, seed + 31 * rank, device=device, ld=ld)
+    y = torch.empty((n_local, ld), dtype=torch.float32, device=device)[:, :F]
+    tmp = [torch.empty((n_local, ld), dtype=torch.float32, device=device)[:, :F] for _ in range(min(max(K - 1, 0), 2))]
     t = torch.tensor([nnz_l], dtype=torch.int64, device=device)
     if world > 1:
-        dist.all_reduce(t)
-    _, info = part.adj_int.schedule()
-    if part.n_halo:
-        part.adj_halo.schedule()
-    return WeakScalingShard(part, x, y, tmp, nnz_l, int(t.item()), n_local + part.n_halo, info, halo_frac)
+        if dist.get_backend(group) == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, group=group)
+    return PartitionedGraph(part, x, y, tmp, F, nnz_l, int(t.item()), n_global)
 
 
 def sharded_edge_construction(pge_edge, Z: torch.Tensor, threshold: float, variant: str = "transductive", group=None):

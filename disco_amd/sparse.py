@@ -389,6 +389,13 @@ class SparseTensor:
             self._sweep = None
         return ws, info
 
+    # ---- locality-aware row order (filled in below) -----------------------------------------------------------
+    def locality_groups(self, iters: int = 8) -> torch.Tensor:
+        raise NotImplementedError
+
+    def set_row_groups(self, groups: Optional[torch.Tensor]) -> None:
+        raise NotImplementedError
+
     def sweep_pays(self, feat: int = WIN_COLS) -> bool:
         """L2-blocked (windowed) propagation re-reads and re-writes the output block once per window, so it
         pays when a row has many entries per window: mean row length >= 8 x number of windows.

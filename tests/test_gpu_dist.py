@@ -17,8 +17,6 @@ pytestmark = pytest.mark.gpu
 
 
 def _worker(rank, world, port, n, F, K, result_dir, dense=False):
-    if dense:
-        os.environ["DISCO_DENSE_HALO"] = "1"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -28,12 +26,11 @@ def _worker(rank, world, port, n, F, K, result_dir, dense=False):
         rowptr, col, val = random_csr(n, n, 9, seed=78, hubs=[(3, 2600), (n - 2, 900)], weighted=True)
         x = np.random.default_rng(6).standard_normal((n, F)).astype(np.float32)
         offs = balanced_row_offsets(torch.from_numpy(rowptr), world)
-        if dense:
-            offs = [g * (n // world) for g in range(world + 1)]
         lo, hi = offs[rank], offs[rank + 1]
         rp = torch.from_numpy(rowptr[lo:hi + 1] - rowptr[lo]).to(dev)
         sl = slice(rowptr[lo], rowptr[hi])
-        part = RowPartition(rp, torch.from_numpy(col[sl]).to(dev), torch.from_numpy(val[sl]).to(dev), offs, rank, world)
+        part = RowPartition(rp, torch.from_numpy(col[sl]).to(dev), torch.from_numpy(val[sl]).to(dev), offs, rank, world,
+                            exchange="dense" if dense else "need")
         assert part.dense == dense
         ld = (F + 31) // 32 * 32
         cur = torch.zeros((hi - lo, ld), device=dev)[:, :F]

@@ -54,7 +54,35 @@ def test_generator_is_deterministic_and_symmetric():
     deg = torch.bincount(r1, minlength=2000)
     assert deg.max() > 8 * deg.float().mean()               # skewed
     r3, c3 = graphgen.powerlaw_edges(500, 4000, 0.0, seed=1, symmetric=False, n_cols=4000)
-    assert int(c3.max()) < 4000 and int(r3.max()) < 500
+    assert int(c3.max()) < 4000 and int(r3.max()) < 500 and r3.numel() == 4000
+    assert r1.numel() == 30000                              # exactly the entry count asked for, not what survived de-duplication
+
+
+def test_partitioned_generator_gives_one_consistent_global_graph():
+    """Every rank generates only its own rows; the union over the ranks is one symmetric graph with exactly the
+    requested number of entries, whatever the world size; the community variant keeps most entries inside a
+    block and scrambling hides that without changing the counts."""
+    n, nnz = 5000, 60000
+    for world in (1, 2, 3, 4):
+        keys = []
+        for rank in range(world):
+            row, col, offs = graphgen.partition_edges(n, nnz, 0.8, 11, world, rank, comm_size=256, mu=0.3, add_diag=True)
+            assert offs == graphgen.block_offsets(n, world) and int(row.max()) < offs[rank + 1] - offs[rank]
+            assert bool((row[1:] * n + col[1:] > row[:-1] * n + col[:-1]).all())        # unique, row-major sorted
+            keys.append((row + offs[rank]) * n + col)
+        key = torch.cat(keys)
+        rr, cc = key // n, key % n
+        assert key.numel() == nnz + n and int((rr != cc).sum()) == nnz
+        s = set(key.tolist())
+        assert all((int(c) * n + int(r)) in s for r, c in zip(rr[::7], cc[::7]))
+        if world > 1:
+            same = ((rr * world // n) == (cc * world // n)).float().mean()
+            assert float(same) > 0.7                        # mu = 0.3: at most ~30 % of the draws leave the block
+    row, col, _ = graphgen.partition_edges(n, nnz, 0.8, 11, comm_size=256, mu=0.3)
+    rs, cs, _ = graphgen.partition_edges(n, nnz, 0.8, 11, comm_size=256, mu=0.3, scramble=True)
+    assert rs.numel() == row.numel() == nnz
+    assert float(((row // 256) == (col // 256)).float().mean()) > 0.5 > 0.1 > float(((rs // 256) == (cs // 256)).float().mean())
+    assert torch.equal(torch.bincount(row, minlength=n).sort().values, torch.bincount(rs, minlength=n).sort().values)
 
 
 def test_no_cpu_fallback():
