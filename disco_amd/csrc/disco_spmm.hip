@@ -205,20 +205,22 @@ template <int VEC> __device__ __forceinline__ typename Vec<VEC>::type vdiv(typen
   }
 }
 
-// Store one vector of an output row; `valid` = columns left in the row at this vector's position.  The last
-// vector of a row whose width is not a multiple of VEC is written element by element, so nothing beyond
-// column F - 1 of y is ever touched (y may be a column view of a wider live matrix).
+// Store vector `idx` of an output row of `nvec` vectors; `tail` (uniform) = number of valid floats in the LAST vector
+// (0 = the row width is a multiple of VEC).  A partial last vector is written element by element, so nothing
+// beyond column F - 1 of y is ever touched (y may be a column view of a wider live matrix).
 template <int VEC>
-__device__ __forceinline__ void store_vec(float* __restrict__ dst, const typename Vec<VEC>::type& a, int valid) {
+__device__ __forceinline__ void store_vec(float* __restrict__ dst, const typename Vec<VEC>::type& a, int idx, int nvec, int tail) {
   if constexpr (VEC == 1) {
     *dst = a;
   } else {
-    if (valid >= VEC) {
-      *reinterpret_cast<typename Vec<VEC>::type*>(dst) = a;
+    if (tail != 0 && idx == nvec - 1) {
+      dst[0] = a[0];
+      if constexpr (VEC == 4) {
+        if (tail > 1) dst[1] = a[1];
+        if (tail > 2) dst[2] = a[2];
+      }
     } else {
-#pragma unroll
-      for (int i = 0; i < VEC - 1; ++i)
-        if (i < valid) dst[i] = a[i];
+      *reinterpret_cast<typename Vec<VEC>::type*>(dst) = a;
     }
   }
 }
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ r
         if (mean && !empty) a = vdiv<VEC>(a, cnt);
         if (accum) a = *dst + a;  // y += A x: the earlier (interior) part first, then this part
       }
-      store_vec<VEC>(reinterpret_cast<float*>(dst), a, fcols - idx * VEC);
+      store_vec<VEC>(reinterpret_cast<float*>(dst), a, idx, nvec, fcols & (VEC - 1));
     }
   }
 }
@@ -281,13 +283,15 @@ __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ r
 // block per window.  Windows are visited in ascending column order, i.e. each row still sums its entries
 // in CSR order: the only difference to k_spmm_rows is that the running sum passes through memory (no
 // rounding: float32 in, float32 out) -- same bits.
-template <int VEC, int G, int NV, int OP, bool HASVAL, bool A24>
-__global__ __launch_bounds__(256, NV == 1 ? 6 : 1) void k_spmm_rows_win(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+// TAIL: the column block's width is not a multiple of VEC, the last vector is stored masked (costs three registers:
+// that variant runs at 5 instead of 6 waves per SIMD rather than spilling).
+template <int VEC, int G, int NV, int OP, bool HASVAL, bool A24, bool TAIL>
+__global__ __launch_bounds__(256, NV == 1 ? (TAIL ? 5 : 6) : 1) void k_spmm_rows_win(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                        const float* __restrict__ val, const float* __restrict__ x,
                                                        int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
                                                        const uint32_t* __restrict__ perm, int64_t first, int64_t count,
                                                        const uint32_t* __restrict__ wbeg, const uint32_t* __restrict__ wend,
-                                                       int first_window, int last_window, int flags, int rpg, int fcols) {
+                                                       int first_window, int last_window, int flags, int rpg) {
   typedef typename Vec<VEC>::type V;
   constexpr int RPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(256, NV == 1 ? 6 : 1) void k_spmm_rows_win(const in
             V a = acc[v];
             if (cnt > 0.0f) a = vdiv<VEC>(a, cnt);
             if (empty_row) a = 0.0f;
-            store_vec<VEC>(yr + (int64_t)idx * VEC, a, fcols - idx * VEC);
+            store_vec<VEC>(yr + (int64_t)idx * VEC, a, idx, nvec, TAIL ? ((flags >> 8) & (VEC - 1)) : 0);
           }
         }
       }
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(512) void k_spmm_hub(const int64_t* __restrict__ ro
       if ((flags & FLAG_ACCUM) && slot < 0) s = *out + s;
     }
     // partial rows live in the caller's workspace (ldp is a multiple of 4): whole vectors; y: masked tail
-    store_vec<VEC>(reinterpret_cast<float*>(out), s, slot < 0 ? fcols - i * VEC : VEC);
+    store_vec<VEC>(reinterpret_cast<float*>(out), s, i, nvec, slot < 0 ? (fcols & (VEC - 1)) : 0);
   }
 }
 
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(256, 4) void k_spmm_sweep(const int64_t* __restrict
         f4* dst = reinterpret_cast<f4*>(y + rs * ldy + (int64_t)lane * 4);
         if ((flags & FLAG_MEAN) && ne > nb) a = vdiv<4>(a, (float)(ne - nb));
         if (flags & FLAG_ACCUM) a = *dst + a;
-        store_vec<4>(reinterpret_cast<float*>(dst), a, fcols - lane * 4);
+        store_vec<4>(reinterpret_cast<float*>(dst), a, lane, nvec, fcols & 3);
       }
     }
   }
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(256) void k_spmm_psync(const int64_t* __restrict__ 
           if (cnt > 0.0f) a = vdiv<VEC>(a, cnt);
         }
         if (flags & FLAG_ACCUM) a = *dst + a;
-        store_vec<VEC>(reinterpret_cast<float*>(dst), a, fcols - gl * VEC);
+        store_vec<VEC>(reinterpret_cast<float*>(dst), a, gl, nvec, fcols & (VEC - 1));
       }
     }
   }
@@ -783,10 +787,16 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       if (rpg > 2) rpg = 2;
       int64_t blocks = (count + 4 * RPW * rpg - 1) / (4 * RPW * rpg);
       if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
+      const bool tail = (a.F % VEC) != 0;
       for (int w = 0; w < P; ++w) {
-        hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, OP, HASVAL, A24>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
-                           a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, wptr + (int64_t)w * s.sweep_count_padded,
-                           wptr + (int64_t)(w + 1) * s.sweep_count_padded, w == 0, w == P - 1, mean, rpg, (int)a.F);
+        if (tail)
+          hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, OP, HASVAL, A24, true>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
+                             a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, wptr + (int64_t)w * s.sweep_count_padded,
+                             wptr + (int64_t)(w + 1) * s.sweep_count_padded, w == 0, w == P - 1, mean | (((int)a.F & 3) << 8), rpg);
+        else
+          hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, OP, HASVAL, A24, false>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
+                             a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, wptr + (int64_t)w * s.sweep_count_padded,
+                             wptr + (int64_t)(w + 1) * s.sweep_count_padded, w == 0, w == P - 1, mean, rpg);
       }
       swept = true;
     }

@@ -59,7 +59,7 @@ def test_two_ranks_one_gpu_matches_global_oracle(F, dense, tmp_path):
         bound = orc.spmm_abs_bound(rowptr, col, val, bound)
     assert np.all(np.abs(got - ref) <= RTOL * K * bound + 1e-30)
     halo = np.array([np.load(tmp_path / f"halo{r}.npy") for r in range(world)])
-    assert halo[:, 0].sum() == halo[:, 1].sum() > 0
+    assert halo[:, 0].sum() > 0 and (dense or halo[:, 0].sum() == halo[:, 1].sum())   # need-only: received == sent
 
 
 def _scorer_worker(rank, world, port, n, d, result_dir):
