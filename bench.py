@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--skew", type=float, default=None)
     ap.add_argument("--sweep", default="auto", choices=["auto", "on", "off"],
                     help="L2-blocked windowed launches (auto: when the graph re-uses source rows enough)")
+    ap.add_argument("--window-kb", type=int, default=0, help="L2 window size of the windowed launches in KiB (0 = library default)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "need", "dense"], help="N > 1: halo exchange")
     ap.add_argument("--extras", default="auto", choices=["auto", "none", "all"],
                     help="extra workloads in the line (auto: products strong scaling, community variants, papers100M at N=8)")
@@ -199,7 +200,8 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
             order = "degree"
         if order == "locality":
             adj.set_row_groups(adj.locality_groups())
-        ws, info = adj.schedule(args.hub_threshold, args.hub_piece, feat=F, sweep={"auto": None, "on": True, "off": False}[args.sweep])
+        ws, info = adj.schedule(args.hub_threshold, args.hub_piece, feat=F, sweep={"auto": None, "on": True, "off": False}[args.sweep],
+                                window_bytes=(args.window_kb << 10) or None)
         sws_bytes = int(lib.disco_spmm_workspace_bytes(info, F))
         sws = torch.empty(max(sws_bytes, 16), dtype=torch.uint8, device=dev)
         stream = _lib.current_stream(dev)

@@ -13,8 +13,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
-SOURCES = ["disco_spmm.hip", "disco_schedule.hip", "disco_norm.hip", "disco_scorer.hip", "disco_build.hip", "disco_gather.hip"]
-HEADERS = ["disco_internal.h", os.path.join(ROOT, "include", "disco_hip.h")]
+SOURCES = ["disco_spmm.hip", "disco_stream.hip", "disco_schedule.hip", "disco_norm.hip", "disco_scorer.hip", "disco_build.hip", "disco_gather.hip"]
+HEADERS = ["disco_internal.h", "disco_spmm_common.h", os.path.join(ROOT, "include", "disco_hip.h")]
 ARCH = "gfx950"
 
 
@@ -56,7 +56,7 @@ def build_lib(force: bool = False, extra_flags=(), name: str = "libdisco_hip.so"
         subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out, *objs]
     if verbose:

@@ -13,18 +13,27 @@ struct Tuning {
   int force_g = 0;    // 0 = automatic
   int force_nv = 0;   // 0 = automatic
   int max_vec = 0;    // 0 = 4
-  int sweep_mode = 2; // with a window table attached: 0 = ignore it, 1 = persistent sweep, 2 = windowed launches, 3 = paced persistent windows
+  int sweep_mode = 2; // with a window table attached: 0 = ignore it, 1 = persistent sweep, 2 = windowed launches, 3 = paced persistent windows, 4 = streaming persistent windows
   int win_cols = 0;   // column block width of the windowed launches (0 = 128)
   int win_rows_per_group = 0;  // consecutive rows one lane group handles per windowed launch (0 = 2, at most 2)
   int sweep_blocks_per_cu = 0;  // 0 = 4
   int psync_pct = 0;  // sweep_mode 3: share of a sync group's waves a wave waits for (0 = 100)
   int psync_polls = 0;  // sweep_mode 3: polls before a wave gives up waiting (0 = 256)
   int addr24 = 1;     // 0 = always 64-bit gather addressing
+  int stream_u = 0;   // sweep_mode 4: gathers in flight per wave (0 = 8; 12 / 16: experiments)
   int xcd_map = 0;    // 1 = the workgroups of one XCD walk one contiguous eighth of the row order (k_spmm_rows)
 };
 
 Tuning& tuning();
 void set_last_hip_error(int e);
+
+// streaming persistent window kernel (disco_stream.hip), one column block of one hop
+struct StreamArgs {
+  const int64_t* rowptr; const int32_t* col; const float* val; const float* x; int64_t ldx; float* y; int64_t ldy;
+  int nvec; int fcols; const uint32_t* perm; int64_t first; int64_t count; const disco_schedule_info* info; int flags;
+  bool addr24; hipStream_t stream;
+};
+int launch_stream(const StreamArgs& a);   // DISCO_EUNSUPPORTED: shape outside the kernel, caller falls back
 
 #define DISCO_HIP_TRY(expr)                                    \
   do {                                                         \

@@ -227,7 +227,9 @@ int disco_sym_threshold_fill(const float* S, int64_t n, int64_t lds, float thres
                              float* edge_weight, void* stream);
 
 /* Benchmark / test knobs: "force_g", "force_nv", "max_vec" (lane-group shape), "sweep_mode" (with a window table
- * attached: 0 ignore it, 1 persistent sweep, 2 windowed launches [default], 3 paced persistent windows),
+ * attached: 0 ignore it, 1 persistent sweep, 2 windowed launches [default], 3 paced persistent windows, 4 streaming
+ * persistent windows [experimental, DESIGN.md 3.4]), "stream_u" (mode 4: gathers in flight per wave), "xcd_map"
+ * (k_spmm_rows: the workgroups of one XCD walk one contiguous eighth of the row order),
  * "win_cols" (column block of modes 2/3, default 128), "win_rpg" (rows per lane group and launch, 1 or 2),
  * "sweep_blocks_per_cu", "psync_pct", "psync_polls" (mode 3 pacing), "addr24" (0 = always 64-bit gather
  * addresses).  Unknown keys return DISCO_EINVAL. */

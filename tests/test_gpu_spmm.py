@@ -401,3 +401,47 @@ def test_set_value_copies_do_not_share_schedule_state():
     assert int(again.sweep_windows) == windows and int(again.sweep_ws) == table
     assert torch.equal(ops.spmm_raw(base, x1, "sum"), y_ref)
     del junk
+
+
+@pytest.mark.parametrize("F", [602, 256, 160])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "sum_acc"])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_streaming_window_kernel_same_bits_as_plain(F, reduce, weighted):
+    """sweep_mode 4 (k_spmm_stream: sums in registers through all windows, one flat gather stream per wave, paced by
+    per-step counters): entries of a row are consumed in CSR order, so every row below the hub threshold must come
+    out with the bits of the one-pass plain kernel -- with windows that hold 0, few and > 64 entries per wave, rows
+    that end in the middle of a chunk, empty rows, and more rows than one sweep of the grid covers."""
+    from disco_amd import _lib, ops
+    lib = _lib.load()
+    n = 9000
+    rowptr, col, val = random_csr(n, n, 70, seed=123, hubs=[(5, 7000), (11, 3000), (8000, 900)], weighted=weighted)
+    x = torch.from_numpy(np.random.default_rng(4).standard_normal((n, F)).astype(np.float32)).to(dev())
+    ld = (F + 31) // 32 * 32
+    xb = torch.zeros((n, ld), device=dev())
+    xb[:, :F] = x
+    y0 = torch.from_numpy(np.random.default_rng(5).standard_normal((n, F)).astype(np.float32)).to(dev())
+
+    def run(adj):
+        out = torch.full((n, ld), 7.0, device=dev())
+        out[:, :F] = y0 if reduce == "sum_acc" else 0.0
+        ops.spmm_raw(adj, xb[:, :F], reduce, out=out[:, :F])
+        return out
+
+    plain = to_adj(rowptr, col, val, n)
+    plain.schedule(8192, 4096, feat=F, sweep=False)
+    y_p = run(plain)
+    win = to_adj(rowptr, col, val, n)
+    _, iw = win.schedule(8192, 4096, feat=F, sweep=True, window_bytes=300 * 512)
+    assert iw.sweep_ws and iw.sweep_windows >= 20 and iw.n_hub_rows == 0
+    lib.disco_set_tuning(b"sweep_mode", 4)
+    lib.disco_set_tuning(b"sweep_blocks_per_cu", 1)        # 256 workgroups x 4 waves x 8 rows < n: several sweeps
+    try:
+        y_s = run(win)
+        lib.disco_set_tuning(b"psync_pct", -1)            # same result without pacing
+        y_u = run(win)
+    finally:
+        lib.disco_set_tuning(b"sweep_mode", 2)
+        lib.disco_set_tuning(b"sweep_blocks_per_cu", 0)
+        lib.disco_set_tuning(b"psync_pct", 0)
+    assert torch.equal(y_p, y_s) and torch.equal(y_p, y_u)
+    assert bool((y_s[:, F:] == 7.0).all())

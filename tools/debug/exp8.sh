@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+run() { echo "== $*"; timeout -k 10 200 python3 bench.py --extras none --no-cpu-baseline --steps 3 "$@" | python3 -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(round(d['ms_per_step'],3), d['config']['l2_windows'], d['roofline']['avg_launch_ms'])" || exit 1; }
+for lead in 1 2 4; do for wkb in 768 1536 3072; do run --window-kb $wkb --tune sweep_mode=4,psync_pct=$lead; done; done
