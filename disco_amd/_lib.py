@@ -57,6 +57,8 @@ _SIGNATURES = {
                                     [C.c_float, c_void_p, c_size_t, c_void_p]),
     "disco_pairscore_block_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64,
                                           c_int, c_void_p]),
+    "disco_pairscore_edges_f32": (c_int, [c_void_p, c_int64, c_int64, C.c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                          c_void_p]),
     "disco_sym_threshold_count": (c_int, [c_void_p, c_int64, c_int64, C.c_float, c_int, c_void_p, c_void_p]),
     "disco_sym_threshold_fill": (c_int, [c_void_p, c_int64, c_int64, C.c_float, c_int, c_void_p, c_int64, c_void_p, c_void_p,
                                          c_void_p]),

@@ -295,6 +295,181 @@ __global__ __launch_bounds__(512) void k_scorer_pairs(const float* __restrict__ 
   }
 }
 
+// ---- fused: score both directions of every pair, symmetrise, threshold, emit edges --------------------------
+// A = (S + S^T)/2 needs S[i][j] and S[j][i] together, so a work item is the PAIR of tiles (i, J) and (J, i): 64
+// forward scores S[i][j] (u = U[i], v = V[j]) followed by the 64 backward scores S[j][i] (u = V[i], v = U[j]: the
+// same h1 = relu(u + v) generator with the two tables swapped), j in one 64-column block J at or right of i's block.
+// Only the upper triangle is walked (both directions of it = the same n^2 pair evaluations as the full matrix);
+// thread p < 64 keeps the forward score, averages it with the backward one and, where it survives the threshold,
+// appends (i, j, a) and (j, i, a) to an UNORDERED edge list (one atomic slot reservation per tile).  The host sorts
+// the list by (row, col) -- the keys are unique, so the final COO is deterministic and in torch.nonzero order --
+// and never sees the n x n matrix.  Each score is the same fmaf chain as in k_scorer_pairs: identical bits.
+template <int H>
+__global__ __launch_bounds__(512) void k_scorer_edges(const float* __restrict__ U, const float* __restrict__ V,
+                                                      const float* __restrict__ W2f, const float* __restrict__ b2f,
+                                                      const float* __restrict__ w3, const float* __restrict__ b3,
+                                                      int64_t n, float thr, int64_t* __restrict__ erow,
+                                                      int64_t* __restrict__ ecol, float* __restrict__ eval, int64_t cap,
+                                                      unsigned long long* __restrict__ counter) {
+  constexpr int HH = H / 2;
+  constexpr int LDA = H + 4;
+  constexpr int NW = H / 32;
+  constexpr int PER = H / 8;
+  constexpr int PSTEP = 512 / H;
+  constexpr int DEPTH = PER < 8 ? PER : 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* red_base = lds + 2 * 64 * LDA;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const bool active = wave < NW;
+  float breg[HH];
+  float bias = 0.0f, w3v = 0.0f;
+  if (active) {
+    const float* wrow = W2f + (int64_t)(32 * wave + r) * H + hh * HH;
+#pragma unroll
+    for (int m = 0; m < HH; m += 4) {
+      f4s t = *reinterpret_cast<const f4s*>(wrow + m);
+      breg[m] = t[0]; breg[m + 1] = t[1]; breg[m + 2] = t[2]; breg[m + 3] = t[3];
+    }
+    bias = b2f[32 * wave + r];
+    w3v = w3[32 * wave + r];
+  }
+  const float b3v = b3[0];
+  const int64_t B = (n + 63) / 64;                      // 64-node blocks
+  const int64_t n_pairs = B * (B + 1) / 2 * 64;         // (block pair bi <= bj) x (row of block bi)
+  const int gk = tid % H, pofs = tid / H;
+  const int gen_off = pofs * LDA + gk;
+  const int mma_off = r * LDA + hh * HH;
+
+  // half-tile `dir` of pair `pi`: which single row supplies u, which 64-row block supplies v
+  auto decode = [&](int64_t pi, int dir, int64_t& i, int64_t& jb, const float*& urow, const float*& vblk, int& pmax) {
+    const int64_t q = pi >> 6;                          // block pair, row-major over the upper triangle
+    // bi = largest b with b * B - b (b - 1) / 2 <= q
+    int64_t bi = (int64_t)(((double)(2 * B + 1) - sqrt((double)(2 * B + 1) * (double)(2 * B + 1) - 8.0 * (double)q)) * 0.5);
+    if (bi < 0) bi = 0;
+    if (bi >= B) bi = B - 1;
+    while (bi > 0 && bi * B - bi * (bi - 1) / 2 > q) --bi;
+    while (bi + 1 < B && (bi + 1) * B - (bi + 1) * bi / 2 <= q) ++bi;
+    const int64_t bj = bi + (q - (bi * B - bi * (bi - 1) / 2));
+    i = bi * 64 + (pi & 63);
+    jb = bj * 64;
+    const int64_t ic = i < n ? i : n - 1;                // rows past the end (last block): computed, never emitted
+    urow = (dir == 0 ? U : V) + ic * H;
+    vblk = (dir == 0 ? V : U) + jb * H;
+    pmax = (int)((n - 1 - jb) < 63 ? (n - 1 - jb) : 63);
+  };
+
+  int64_t pi = blockIdx.x;
+  if (pi >= n_pairs) return;
+  int dir = 0;
+  {
+    int64_t i, jb; const float *urow, *vblk; int pmax;
+    decode(pi, 0, i, jb, urow, vblk, pmax);
+    const float u = urow[gk];
+    const float* vb = vblk + gk;
+#pragma unroll 8
+    for (int q = 0; q < PER; ++q) {
+      int p = q * PSTEP + pofs;
+      const int pc = p < pmax ? p : pmax;
+      lds[gen_off + q * PSTEP * LDA] = fmaxf(u + vb[pc * H], 0.0f);
+    }
+  }
+  __syncthreads();
+  int buf = 0;
+  float fwd = 0.0f;                                      // forward score of pair (i, jb + tid), threads < 64
+  while (pi < n_pairs) {
+    int64_t i, jb; const float *urow_c, *vblk_c; int pmax_c;
+    decode(pi, dir, i, jb, urow_c, vblk_c, pmax_c);
+    // the half-tile generated while this one is multiplied (the very last one regenerates itself: harmless)
+    int64_t pin = dir == 0 ? pi : pi + gridDim.x;
+    const int dirn = dir ^ 1;
+    if (pin >= n_pairs) pin = pi;
+    int64_t in_, jbn; const float *urow, *vblk; int pmax;
+    decode(pin, pin == pi && dir == 1 ? 1 : dirn, in_, jbn, urow, vblk, pmax);
+    const float un = urow[gk];
+    const float* vb = vblk + gk;
+    const float* a_cur = lds + buf * (64 * LDA);
+    float* a_nxt = lds + (buf ^ 1) * (64 * LDA) + gen_off;
+    float ring[DEPTH];
+    f32x16 acc0 = {0}, acc1 = {0};
+    const float* a0 = a_cur + mma_off;
+    const float* a1 = a0 + 32 * LDA;
+    f4s x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+    if (active) {
+      x0 = *reinterpret_cast<const f4s*>(a0);
+      x1 = *reinterpret_cast<const f4s*>(a1);
+    }
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      {
+        const int p = it * PSTEP + pofs;
+        const int pc = p < pmax ? p : pmax;
+        ring[it % DEPTH] = vb[pc * H];
+      }
+      if (active) {
+        const int m = 4 * it;
+        f4s n0 = x0, n1 = x1;
+        if (m + 4 < HH) {
+          n0 = *reinterpret_cast<const f4s*>(a0 + m + 4);
+          n1 = *reinterpret_cast<const f4s*>(a1 + m + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[q], breg[m + q], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[q], breg[m + q], acc1, 0, 0, 0);
+        }
+        x0 = n0; x1 = n1;
+      }
+      if (it >= DEPTH - 1) {
+        const int e = it - (DEPTH - 1);
+        a_nxt[e * PSTEP * LDA] = fmaxf(un + ring[e % DEPTH], 0.0f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int e = PER - (DEPTH - 1); e < PER; ++e) a_nxt[e * PSTEP * LDA] = fmaxf(un + ring[e % DEPTH], 0.0f);
+    float* red = red_base + buf * (8 * 64);
+    if (active) {
+      const float s0 = reduce_features(acc0, bias, w3v, r);
+      const float s1 = reduce_features(acc1, bias, w3v, r);
+      const int g = r & 15;
+      const int prow = (g & 3) + 8 * (g >> 2) + 4 * hh;
+      if (r < 16) red[wave * 64 + prow] = s0;
+      else red[wave * 64 + 32 + prow] = s1;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float s = b3v;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[w * 64 + tid];
+      s = 1.0f / (1.0f + expf(-s));
+      if (dir == 0) {
+        fwd = s;
+      } else {
+        const int64_t j = jb + tid;
+        const float a = (fwd + s) / 2.0f;                 // (S[i][j] + S[j][i]) / 2, the operand order of the dense path
+        const bool keep = i < n && j < n && j > i && !(a < thr) && a != 0.0f;   // `A[A < thr] = 0` then nonzero()
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+          unsigned long long base = 0;
+          if (tid == 0) base = atomicAdd(counter, 2ull * (unsigned long long)__popcll(m));
+          base = ((unsigned long long)__shfl((int)(base >> 32), 0) << 32) | (unsigned int)__shfl((int)(base & 0xffffffffu), 0);
+          if (keep) {
+            const int64_t pos = (int64_t)base + 2 * __popcll(m & ((1ull << tid) - 1ull));
+            // beyond the capacity nothing is written: the counter still runs, the caller sees the overflow
+            if (pos < cap) { erow[pos] = i; ecol[pos] = j; eval[pos] = a; }
+            if (pos + 1 < cap) { erow[pos + 1] = j; ecol[pos + 1] = i; eval[pos + 1] = a; }
+          }
+        }
+      }
+    }
+    buf ^= 1;
+    if (dir == 1) pi += gridDim.x;
+    dir ^= 1;
+  }
+}
+
 // ---- post-processing: symmetrise, threshold, diagonal, compaction ------------------------------------
 // variant 0 transductive: A = (S + S^T)/2; A[A < thr] = 0; diag = 1        (LargeScaleCondensing.py:306-308)
 // variant 1 inductive   : A = (S + S^T)/2; diag = 1; A[A < thr] = 0        (LargeScaleCondensing_induct.py:300-302)
@@ -389,9 +564,13 @@ static int launch_pairs(const char* w, const ScorerWs& L, int64_t i0, int64_t i1
   int64_t blocks = tiles < 256 * 4 ? tiles : 256 * 4;
   if (blocks < 1) return DISCO_OK;
   const size_t lds_bytes = (size_t)(2 * 64 * (H + 4) + 2 * 8 * 64) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scorer_pairs<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds_bytes);
-  if (e != hipSuccess) { set_last_hip_error((int)e); return DISCO_EHIP; }
+  static bool attr_set = false;      // per instantiation: raised once, not on every launch
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scorer_pairs<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) { set_last_hip_error((int)e); return DISCO_EHIP; }
+    attr_set = true;
+  }
   hipLaunchKernelGGL((k_scorer_pairs<H>), dim3((unsigned)blocks), dim3(512), lds_bytes, s,
                      reinterpret_cast<const float*>(w + L.off_u), reinterpret_cast<const float*>(w + L.off_v),
                      reinterpret_cast<const float*>(w + L.off_w2), reinterpret_cast<const float*>(w + L.off_b2),
@@ -438,4 +617,48 @@ extern "C" int disco_sym_threshold_fill(const float* S, int64_t n, int64_t lds, 
                      rowstart, E, edge_index, edge_weight);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
+}
+
+template <int H>
+static int launch_edges(const char* w, const ScorerWs& L, int64_t n, float thr, int64_t* erow, int64_t* ecol, float* eval,
+                        int64_t cap, unsigned long long* counter, hipStream_t s) {
+  const int64_t B = (n + 63) / 64;
+  const int64_t n_pairs = B * (B + 1) / 2 * 64;
+  int64_t blocks = n_pairs < 256 * 4 ? n_pairs : 256 * 4;
+  if (blocks < 1) return DISCO_OK;
+  const size_t lds_bytes = (size_t)(2 * 64 * (H + 4) + 2 * 8 * 64) * sizeof(float);
+  static bool attr_set = false;      // per instantiation: the dynamic LDS limit is raised once, not on every launch
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scorer_edges<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) { set_last_hip_error((int)e); return DISCO_EHIP; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_scorer_edges<H>), dim3((unsigned)blocks), dim3(512), lds_bytes, s,
+                     reinterpret_cast<const float*>(w + L.off_u), reinterpret_cast<const float*>(w + L.off_v),
+                     reinterpret_cast<const float*>(w + L.off_w2), reinterpret_cast<const float*>(w + L.off_b2),
+                     reinterpret_cast<const float*>(w + L.off_w3), reinterpret_cast<const float*>(w + L.off_b3), n, thr, erow, ecol,
+                     eval, cap, counter);
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}
+
+extern "C" int disco_pairscore_edges_f32(const void* ws, int64_t n, int64_t H, float threshold, int64_t* edge_row,
+                                         int64_t* edge_col, float* edge_val, int64_t capacity, int64_t* count_dev,
+                                         void* stream_) {
+  if (!ws || n < 0 || capacity < 0 || !count_dev) return DISCO_EINVAL;
+  if (capacity > 0 && (!edge_row || !edge_col || !edge_val)) return DISCO_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  DISCO_HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(int64_t), s));
+  if (n == 0) return DISCO_OK;
+  ScorerWs L = scorer_layout(n, H);
+  const char* w = static_cast<const char*>(ws);
+  unsigned long long* counter = reinterpret_cast<unsigned long long*>(count_dev);
+  switch (H) {
+    case 32: return launch_edges<32>(w, L, n, threshold, edge_row, edge_col, edge_val, capacity, counter, s);
+    case 64: return launch_edges<64>(w, L, n, threshold, edge_row, edge_col, edge_val, capacity, counter, s);
+    case 128: return launch_edges<128>(w, L, n, threshold, edge_row, edge_col, edge_val, capacity, counter, s);
+    case 256: return launch_edges<256>(w, L, n, threshold, edge_row, edge_col, edge_val, capacity, counter, s);
+    default: return DISCO_EUNSUPPORTED;
+  }
 }

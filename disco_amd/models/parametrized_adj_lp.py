@@ -107,10 +107,53 @@ class PGE_Edge(nn.Module):
         return self.score_block(Z, (0, Z.shape[0]), None, logits)
 
     @torch.no_grad()
-    def edge_construction(self, Z: torch.Tensor, threshold: float, variant: str = "transductive"):
-        """(edge_index int64 [2, E], edge_weight float32 [E]) of the condensed graph, on the GPU:
-        scores -> (S + S^T)/2 -> threshold / unit diagonal in the order of `variant` -> nonzero."""
-        return self.edges_from_scores(self.score_all_pairs(Z), threshold, variant)
+    def edge_construction(self, Z: torch.Tensor, threshold: float, variant: str = "transductive", fused: bool = True,
+                          capacity: Optional[int] = None):
+        """(edge_index int64 [2, E], edge_weight float32 [E]) of the condensed graph, on the GPU: scores ->
+        (S + S^T)/2 -> threshold / unit diagonal in the order of `variant` -> entries in ``torch.nonzero`` order
+        (/root/reference/LargeScaleCondensing.py:304-310, _induct.py:298-304, _Sampled.py:266-285).
+
+        fused=True (default): ``disco_pairscore_edges_f32`` scores both directions of every pair, thresholds in the
+        kernel and emits only the surviving edges; the n x n matrix (2.5 GB at n = 25 000) is never written or
+        re-read.  fused=False is the dense path (score matrix + ``edges_from_scores``); both give identical bits."""
+        if not fused:
+            return self.edges_from_scores(self.score_all_pairs(Z), threshold, variant)
+        v = _VARIANTS[variant]
+        ws, n, H, keep = self._prepare(Z)
+        lib = _lib.load()
+        dev = Z.device
+        cap = int(capacity) if capacity is not None else min(n * n, max(1 << 22, 64 * n))
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            while True:
+                erow = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+                ecol = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+                evl = torch.empty(max(cap, 1), dtype=torch.float32, device=dev)
+                _lib.check(lib.disco_pairscore_edges_f32(_lib.ptr(ws), n, H, float(threshold), _lib.ptr(erow), _lib.ptr(ecol),
+                                                         _lib.ptr(evl), cap, _lib.ptr(count), _lib.current_stream(dev)),
+                           "disco_pairscore_edges_f32")
+                E = int(count.item())
+                if E <= cap:
+                    break
+                cap = E                      # denser than expected: one more pass with exactly enough room
+        erow, ecol, evl = erow[:E], ecol[:E], evl[:E]
+        # unit diagonal: transductive sets it after thresholding, inductive before (a unit entry survives unless 1 < thr)
+        if v == 0 or (v == 1 and not (1.0 < float(threshold))):
+            d = torch.arange(n, device=dev)
+            erow, ecol = torch.cat([erow, d]), torch.cat([ecol, d])
+            evl = torch.cat([evl, torch.ones(n, dtype=torch.float32, device=dev)])
+        if erow.numel():
+            from ..sparse import coo_to_csr
+            rp, c32, vals = coo_to_csr(erow, ecol, evl, (n, n), dup="keep")       # device radix sort by (row, col)
+            rows = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
+            ei, ew = torch.stack([rows, c32.to(torch.int64)]), vals
+        else:
+            ei, ew = torch.empty((2, 0), dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.float32, device=dev)
+        if variant == "sampled":
+            loops = torch.arange(n, device=dev)
+            ei = torch.cat([ei, torch.stack([loops, loops])], dim=1)
+            ew = torch.cat([ew, torch.ones(n, device=dev)])
+        return ei, ew
 
     @staticmethod
     @torch.no_grad()

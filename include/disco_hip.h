@@ -212,6 +212,17 @@ int disco_pairscore_prepare_f32(const float* Z, int64_t n, int64_t D, int64_t ld
 int disco_pairscore_block_f32(const void* ws, int64_t n, int64_t H, int64_t i0, int64_t i1, int64_t j0,
                               int64_t j1, float* out, int64_t ldo, int apply_sigmoid, void* stream);
 
+/* Fused edge construction: scores BOTH directions of every pair i < j (the same n^2 pair evaluations as the full
+ * matrix), forms a = (S[i][j] + S[j][i]) / 2 and, where !(a < threshold) and a != 0, appends (i, j, a) and (j, i, a)
+ * to an UNORDERED list -- the n x n matrix of /root/reference/LargeScaleCondensing.py:291,304-307 is never
+ * materialised.  *count_dev (device int64, zeroed by the call) receives the number of entries produced; entries
+ * beyond `capacity` are counted but not written, so count > capacity means: call again with room for `count`.
+ * The diagonal is NOT emitted (variants differ: the caller adds the n unit entries it wants), and the list is in
+ * no particular order: sort it by (row, col) -- keys are unique -- for the torch.nonzero order of the dense path
+ * (disco_coo_to_csr with DISCO_COO_DUP_KEEP does that).  Bitwise the same values as the dense path. */
+int disco_pairscore_edges_f32(const void* ws, int64_t n, int64_t H, float threshold, int64_t* edge_row,
+                              int64_t* edge_col, float* edge_val, int64_t capacity, int64_t* count_dev, void* stream);
+
 /* Post-processing of the n x n score matrix S into a COO edge list in torch.nonzero (row-major) order.
  * A = (S + S^T)/2, then
  *   variant 0 (transductive, LargeScaleCondensing.py:306-308):  A[A<thr]=0; diag=1

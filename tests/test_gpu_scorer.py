@@ -127,3 +127,28 @@ def test_full_size_c4_properties():
     off = ~diag
     a = (S[ei[0][off], ei[1][off]] + S[ei[1][off], ei[0][off]]) / 2.0
     assert torch.equal(ew[off], a) and bool((a >= thr).all())
+
+
+@pytest.mark.parametrize("n,nfeat,nhid", [(333, 12, 64), (1000, 20, 256), (64, 7, 32), (130, 5, 128)])
+@pytest.mark.parametrize("variant", ["transductive", "inductive", "sampled"])
+def test_fused_edge_construction_equals_dense_path(n, nfeat, nhid, variant):
+    """disco_pairscore_edges_f32 (scores both directions of a pair, symmetrises, thresholds and emits edges without
+    the n x n matrix) must give the dense path's edge list bit for bit, in torch.nonzero order -- at several
+    thresholds (incl. 1.5: an inductive graph loses its diagonal), with n not a multiple of the 64-node tile, and when
+    the first pass overflows its edge buffer."""
+    from disco_amd.models.parametrized_adj_lp import PGE_Edge
+    torch.manual_seed(n + nhid)
+    m = PGE_Edge(nfeat=nfeat, nhid=nhid).to(DEV).eval()
+    with torch.no_grad():
+        for bn in m.bns:
+            bn.running_mean.normal_(0, 0.3)
+            bn.running_var.uniform_(0.5, 1.5)
+        m.layers[-1].weight.mul_(4.0)
+    Z = torch.randn(n, nfeat, device=DEV)
+    for thr in (0.5, 0.9, 1.5, 0.0):
+        ei_d, ew_d = m.edge_construction(Z, thr, variant, fused=False)
+        ei_f, ew_f = m.edge_construction(Z, thr, variant)
+        assert torch.equal(ei_d, ei_f) and torch.equal(ew_d, ew_f), (thr, ei_d.shape, ei_f.shape)
+    ei_s, ew_s = m.edge_construction(Z, 0.5, variant, capacity=10)         # overflow -> second pass
+    ei_d, ew_d = m.edge_construction(Z, 0.5, variant, fused=False)
+    assert ei_d.shape[1] > 10 and torch.equal(ei_d, ei_s) and torch.equal(ew_d, ew_s)

@@ -445,3 +445,81 @@ def test_streaming_window_kernel_same_bits_as_plain(F, reduce, weighted):
         lib.disco_set_tuning(b"psync_pct", 0)
     assert torch.equal(y_p, y_s) and torch.equal(y_p, y_u)
     assert bool((y_s[:, F:] == 7.0).all())
+
+
+def _oracle_row_sample(adj, x, y, n_sample, seed, what):
+    """Rows of y against the float64 oracle on the sub-matrix of those rows (columns renumbered to the rows of x they touch)."""
+    rp = adj.storage.rowptr()
+    n = adj.size(0)
+    rows = torch.from_numpy(np.sort(np.random.default_rng(seed).choice(n, n_sample, replace=False))).to(rp.device)
+    beg, end = rp[rows], rp[rows + 1]
+    cnt = end - beg
+    sub_rp = torch.zeros(n_sample + 1, dtype=torch.int64, device=rp.device)
+    torch.cumsum(cnt, 0, out=sub_rp[1:])
+    idx = torch.repeat_interleave(beg - sub_rp[:-1], cnt) + torch.arange(int(sub_rp[-1]), device=rp.device)
+    cols = adj._col32[idx].to(torch.int64)
+    vals = adj.storage.value()[idx]
+    uniq, inv = torch.unique(cols, return_inverse=True)
+    y64, bound = c_oracle.spmm_csr_f64acc(sub_rp.cpu().numpy(), inv.cpu().numpy(), vals.cpu().numpy(), x[uniq].cpu().numpy(),
+                                          want_bound=True)
+    assert_fwd_close(y[rows].cpu().numpy(), y64, bound, what=what)
+
+
+def test_full_size_properties_products_shaped():
+    """BASELINE config 3 (ogbn-products shape: N = 2 449 029, nnz = 61 859 140 + N self-loops, F = 100) at full size on
+    one GPU: exact entry count, linearity, A*1 == row sums (hub row of several 10^5 entries included), a 2048-row
+    sample against the float64 oracle, and the same bits with the XCD-aware block order."""
+    from disco_amd import SparseTensor, _lib, graphgen, ops, utils
+    spec = graphgen.SPECS["products"]
+    n, F = spec.n_nodes, spec.feat
+    row, col = graphgen.powerlaw_edges(n, spec.nnz, spec.skew, spec.seed, device=dev())
+    assert row.numel() == spec.nnz
+    adj = utils.normalize_adj_csr(SparseTensor(row=row, col=col, value=None, sparse_sizes=(n, n), is_sorted=True))
+    del row, col
+    assert adj.nnz() == spec.nnz + n
+    x = graphgen.features(n, F, spec.seed, device=dev(), ld=128)
+    z = graphgen.features(n, F, spec.seed + 1, device=dev(), ld=128)
+    y = ops.spmm_raw(adj, x, "sum")
+    yz = ops.spmm_raw(adj, z, "sum")
+    ylin = ops.spmm_raw(adj, 0.5 * x - 2.0 * z, "sum")
+    scale = ops.spmm_raw(adj, x.abs() + 2 * z.abs(), "sum")
+    assert bool(((ylin - (0.5 * y - 2.0 * yz)).abs() <= 2e-5 * scale + 1e-30).all())
+    del yz, ylin, scale, z
+    # float64 row sums by a prefix sum (an index_add_ would serialise its atomics on the hub row)
+    cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev()), torch.cumsum(adj.storage.value().double(), 0)])
+    rs = cs[adj.storage.rowptr()[1:]] - cs[adj.storage.rowptr()[:-1]]
+    a1 = ops.spmm_raw(adj, torch.ones(n, 4, device=dev()), "sum")[:, 0].double()
+    assert bool(((a1 - rs).abs() <= 1e-5 * rs.abs() + 1e-9).all())
+    _oracle_row_sample(adj, x, y, 2048, 0, "products-shaped sample")
+    lib = _lib.load()
+    lib.disco_set_tuning(b"xcd_map", 1)
+    try:
+        assert torch.equal(ops.spmm_raw(adj, x, "sum"), y)
+    finally:
+        lib.disco_set_tuning(b"xcd_map", 0)
+    y2 = ops.khop(adj, x, 2)
+    assert bool(torch.isfinite(y2).all())
+
+
+def test_papers100m_shaped_row_shard_with_global_columns():
+    """BASELINE config 5: rank 3's row block of the 8-way partition of the ogbn-papers100M-shaped graph (13.9 M rows,
+    ~202 M entries) with GLOBAL column ids into the 111 M-row feature table -- the rectangular operand a row partition
+    hands to disco_spmm_csr_f32 (int32 columns up to 1.1e8, 64-bit gather addresses: the table is 14 GB at the F = 32 used
+    here).  A*1 == row sums and a row sample against the float64 oracle."""
+    from disco_amd import SparseTensor, graphgen, ops
+    spec = graphgen.SPECS["papers100M"]
+    n_global, world, rank, F = spec.n_nodes, 8, 3, 32
+    row, col, offs = graphgen.partition_edges(n_global, spec.nnz, spec.skew, spec.seed, world, rank, device=dev())
+    n_local = offs[rank + 1] - offs[rank]
+    assert abs(row.numel() - spec.nnz // world) < 0.02 * spec.nnz // world and int(col.max()) > n_global - n_global // 64
+    deg = torch.bincount(row, minlength=n_local).to(torch.float32)
+    val = (1.0 / deg.clamp(min=1.0))[row]                      # row-stochastic weights: A * 1 == 1 on non-empty rows
+    adj = SparseTensor(row=row, col=col, value=val, sparse_sizes=(n_local, n_global), is_sorted=True)
+    del row, col, val
+    x = graphgen.features(n_global, F, spec.seed, device=dev())
+    y = ops.spmm_raw(adj, x, "sum")
+    assert y.shape == (n_local, F)
+    _oracle_row_sample(adj, x, y, 1024, 1, "papers100M-shaped shard sample")
+    a1 = ops.spmm_raw(adj, torch.ones(n_global, 4, device=dev()), "sum")[:, 0]
+    want = (deg > 0).to(torch.float32)
+    assert bool(((a1 - want).abs() <= 1e-4).all())
