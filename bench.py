@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--graph", default="config", choices=["config", "community", "community-scrambled"],
                     help="generator variant (graphgen.py): locality-free configuration model [headline], LFR-style "
                          "communities in partitioner order, or the same behind a random relabelling (N = 1 only)")
+    ap.add_argument("--locality-max-group", type=int, default=8192, help="group size bound of --order locality (0: none)")
+    ap.add_argument("--locality-sweeps", type=int, default=8, help="label-propagation sweeps of --order locality")
     ap.add_argument("--order", default="auto", choices=["auto", "degree", "locality"],
                     help="row schedule: degree-binned, or grouped by the device-side locality pass first")
     ap.add_argument("--hops", type=int, default=2)
@@ -199,7 +201,20 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
         if order == "auto":
             order = "degree"
         if order == "locality":
-            adj.set_row_groups(adj.locality_groups())
+            torch.cuda.synchronize()
+            t0 = time.time()
+            groups = adj.locality_groups(args.locality_sweeps, args.locality_max_group)
+            torch.cuda.synchronize()
+            t_pass = time.time() - t0
+            r, c, _ = adj.coo()
+            cfg["locality_pass"] = {"sweeps": args.locality_sweeps, "max_group": args.locality_max_group, "seconds": round(t_pass, 3),
+                                    "groups": int(torch.unique(groups).numel()),
+                                    "edges_inside_a_group": round(float((groups[r] == groups[c]).float().mean()), 4)}
+            del r, c
+            adj.set_row_groups(groups)
+            if "xcd_map" not in args.tune:      # runs of 128 workgroups of the grouped order per XCD (reset below)
+                _lib.check(lib.disco_set_tuning(b"xcd_map", 128), "disco_set_tuning(xcd_map)")
+                cfg["xcd_map"] = 128
         ws, info = adj.schedule(args.hub_threshold, args.hub_piece, feat=F, sweep={"auto": None, "on": True, "off": False}[args.sweep],
                                 window_bytes=(args.window_kb << 10) or None)
         sws_bytes = int(lib.disco_spmm_workspace_bytes(info, F))
@@ -253,6 +268,8 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
     t_setup = time.time() - t_setup
 
     elapsed = ctx.timed(step, warmup, steps)
+    if cfg.get("xcd_map"):
+        _lib.check(lib.disco_set_tuning(b"xcd_map", 0), "disco_set_tuning(xcd_map)")
     durs_ms = [a.elapsed_time(b) for a, b in events]
     hop_ms = sum(durs_ms) / max(len(durs_ms), 1)
     algo = b_min_bytes(nnz, n_local, F)                      # this rank's share per hop

@@ -35,6 +35,11 @@ _SIGNATURES = {
     "disco_schedule_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
     "disco_schedule_build": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_size_t,
                                      C.POINTER(ScheduleInfo), c_void_p]),
+    "disco_schedule_grouped_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "disco_schedule_build_grouped": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_size_t,
+                                             C.POINTER(ScheduleInfo), c_void_p]),
+    "disco_locality_workspace_bytes": (c_size_t, [c_int64]),
+    "disco_locality_labels": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "disco_sweep_workspace_bytes": (c_size_t, [C.POINTER(ScheduleInfo), c_int64, c_int64]),
     "disco_sweep_build": (c_int, [c_void_p, c_void_p, c_void_p, C.POINTER(ScheduleInfo), c_int64, c_int64, c_void_p, c_size_t,
                                   c_void_p]),

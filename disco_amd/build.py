@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
-SOURCES = ["disco_spmm.hip", "disco_stream.hip", "disco_schedule.hip", "disco_norm.hip", "disco_scorer.hip", "disco_build.hip", "disco_gather.hip"]
+SOURCES = ["disco_spmm.hip", "disco_stream.hip", "disco_schedule.hip", "disco_norm.hip", "disco_scorer.hip", "disco_build.hip", "disco_gather.hip", "disco_locality.hip"]
 HEADERS = ["disco_internal.h", "disco_spmm_common.h", os.path.join(ROOT, "include", "disco_hip.h")]
 ARCH = "gfx950"
 

@@ -41,8 +41,10 @@ struct Counters {
   unsigned long long n_multi;
 };
 
+template <typename KEY>
 __global__ void k_row_keys(const int64_t* __restrict__ rowptr, int64_t n_rows, int64_t hub_threshold, int natural,
-                           uint8_t* __restrict__ keys, uint32_t* __restrict__ rows, Counters* cnt) {
+                           const uint32_t* __restrict__ row_group, KEY* __restrict__ keys, uint32_t* __restrict__ rows,
+                           Counters* cnt) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long nnz = 0;
   bool hub = false;
@@ -54,7 +56,13 @@ __global__ void k_row_keys(const int64_t* __restrict__ rowptr, int64_t n_rows, i
     else if (natural) key = 1;
     else if (nnz == 0) key = 63;
     else { int k = 62 - (63 - __clzll((long long)nnz)); key = (uint8_t)(k < 2 ? 2 : k); }
-    keys[r] = key;
+    if constexpr (sizeof(KEY) == 8) {
+      // locality-grouped order: hubs first, then rows group by group (rows of one group share neighbours: their
+      // gathers hit the same cache), heavier rows first inside a group
+      keys[r] = hub ? (KEY)0 : (((KEY)row_group[r] + 1) << 8) | (KEY)key;
+    } else {
+      keys[r] = key;
+    }
     rows[r] = (uint32_t)r;
   }
   // one atomic per wave
@@ -137,7 +145,7 @@ struct Layout {
   int64_t total;
 };
 
-static int make_layout(int64_t n_rows, int64_t nnz, int64_t T, int64_t P, Layout& L) {
+static int make_layout(int64_t n_rows, int64_t nnz, int64_t T, int64_t P, Layout& L, bool grouped = false) {
   L.n_hub_max = nnz / (T + 1);
   if (L.n_hub_max > n_rows) L.n_hub_max = n_rows;
   L.n_piece_max = nnz / P + L.n_hub_max + 1;
@@ -153,8 +161,8 @@ static int make_layout(int64_t n_rows, int64_t nnz, int64_t T, int64_t P, Layout
   L.off_multi_first = take(8 * (L.n_hub_max + 2));
   // build-time scratch
   L.off_cnt = take(sizeof(Counters));
-  L.off_keys_in = take(n_rows);
-  L.off_keys_out = take(n_rows);
+  L.off_keys_in = take(grouped ? 8 * n_rows : n_rows);
+  L.off_keys_out = take(grouped ? 8 * n_rows : n_rows);
   L.off_rows_in = take(4 * n_rows);
   L.off_cntarr = take(8 * (L.n_hub_max + 1));
   L.off_scan_a = take(8 * (L.n_hub_max + 1));
@@ -163,8 +171,10 @@ static int make_layout(int64_t n_rows, int64_t nnz, int64_t T, int64_t P, Layout
   L.sort_tmp = 0;
   L.scan_tmp = 0;
   if (n_rows > 0) {
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, L.sort_tmp, (const uint8_t*)nullptr, (uint8_t*)nullptr,
-                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n_rows, 0, 8);
+    hipError_t e = grouped ? rocprim::radix_sort_pairs(nullptr, L.sort_tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n_rows, 0, 41)
+                           : rocprim::radix_sort_pairs(nullptr, L.sort_tmp, (const uint8_t*)nullptr, (uint8_t*)nullptr,
+                                                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n_rows, 0, 8);
     if (e != hipSuccess) { set_last_hip_error((int)e); return DISCO_EHIP; }
   }
   if (L.n_hub_max > 0) {
@@ -181,19 +191,45 @@ static int make_layout(int64_t n_rows, int64_t nnz, int64_t T, int64_t P, Layout
 
 using namespace disco;
 
-extern "C" size_t disco_schedule_workspace_bytes(int64_t n_rows, int64_t nnz, int64_t hub_threshold, int64_t hub_piece) {
+static size_t schedule_ws_bytes(int64_t n_rows, int64_t nnz, int64_t hub_threshold, int64_t hub_piece, bool grouped) {
   if (n_rows < 0 || nnz < 0) return 0;
   if (hub_threshold < 0) hub_threshold = -hub_threshold;
   int64_t T = hub_threshold > 0 ? hub_threshold : default_hub_threshold(nnz);
   int64_t P = hub_piece > 0 ? hub_piece : default_hub_piece(T);
   Layout L;
-  if (make_layout(n_rows, nnz, T, P, L) != DISCO_OK) return 0;
+  if (make_layout(n_rows, nnz, T, P, L, grouped) != DISCO_OK) return 0;
   return (size_t)L.total;
 }
+
+extern "C" size_t disco_schedule_workspace_bytes(int64_t n_rows, int64_t nnz, int64_t hub_threshold, int64_t hub_piece) {
+  return schedule_ws_bytes(n_rows, nnz, hub_threshold, hub_piece, false);
+}
+
+extern "C" size_t disco_schedule_grouped_workspace_bytes(int64_t n_rows, int64_t nnz, int64_t hub_threshold, int64_t hub_piece) {
+  return schedule_ws_bytes(n_rows, nnz, hub_threshold, hub_piece, true);
+}
+
+static int schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz, int64_t hub_threshold, int64_t hub_piece,
+                          const uint32_t* row_group, void* sched_ws, size_t sched_ws_bytes, disco_schedule_info* info,
+                          void* stream_);
 
 extern "C" int disco_schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz, int64_t hub_threshold,
                                     int64_t hub_piece, void* sched_ws, size_t sched_ws_bytes,
                                     disco_schedule_info* info, void* stream_) {
+  return schedule_build(rowptr, n_rows, nnz, hub_threshold, hub_piece, nullptr, sched_ws, sched_ws_bytes, info, stream_);
+}
+
+extern "C" int disco_schedule_build_grouped(const int64_t* rowptr, int64_t n_rows, int64_t nnz, int64_t hub_threshold,
+                                            int64_t hub_piece, const uint32_t* row_group, void* sched_ws,
+                                            size_t sched_ws_bytes, disco_schedule_info* info, void* stream_) {
+  if (!row_group && n_rows > 0) return DISCO_EINVAL;
+  return schedule_build(rowptr, n_rows, nnz, hub_threshold, hub_piece, row_group, sched_ws, sched_ws_bytes, info, stream_);
+}
+
+static int schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz, int64_t hub_threshold, int64_t hub_piece,
+                          const uint32_t* row_group, void* sched_ws, size_t sched_ws_bytes, disco_schedule_info* info,
+                          void* stream_) {
+  const bool grouped = row_group != nullptr;
   if (!info || n_rows < 0 || nnz < 0 || n_rows > 0xffffffffLL) return DISCO_EINVAL;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   int natural = 0;
@@ -202,7 +238,7 @@ extern "C" int disco_schedule_build(const int64_t* rowptr, int64_t n_rows, int64
   int64_t P = hub_piece > 0 ? hub_piece : default_hub_piece(T);
   if (P < 64) P = 64;
   Layout L;
-  int rc = make_layout(n_rows, nnz, T, P, L);
+  int rc = make_layout(n_rows, nnz, T, P, L, grouped);
   if (rc != DISCO_OK) return rc;
   if ((size_t)L.total > sched_ws_bytes) return DISCO_EWORKSPACE;
   if (n_rows > 0 && (!rowptr || !sched_ws)) return DISCO_EINVAL;
@@ -215,8 +251,6 @@ extern "C" int disco_schedule_build(const int64_t* rowptr, int64_t n_rows, int64
 
   char* ws = static_cast<char*>(sched_ws);
   Counters* cnt = reinterpret_cast<Counters*>(ws + L.off_cnt);
-  uint8_t* keys_in = reinterpret_cast<uint8_t*>(ws + L.off_keys_in);
-  uint8_t* keys_out = reinterpret_cast<uint8_t*>(ws + L.off_keys_out);
   uint32_t* rows_in = reinterpret_cast<uint32_t*>(ws + L.off_rows_in);
   uint32_t* perm = reinterpret_cast<uint32_t*>(ws + L.off_perm);
   void* tmp = ws + L.off_tmp;
@@ -224,13 +258,25 @@ extern "C" int disco_schedule_build(const int64_t* rowptr, int64_t n_rows, int64
   DISCO_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(Counters), stream));
   {
     int64_t blocks = (n_rows + 255) / 256;
-    hipLaunchKernelGGL(k_row_keys, dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, n_rows, T, natural, keys_in,
-                       rows_in, cnt);
-    DISCO_CHECK_LAUNCH();
+    size_t sort_tmp = L.sort_tmp;
+    if (grouped) {
+      uint64_t* keys_in = reinterpret_cast<uint64_t*>(ws + L.off_keys_in);
+      uint64_t* keys_out = reinterpret_cast<uint64_t*>(ws + L.off_keys_out);
+      hipLaunchKernelGGL(k_row_keys<uint64_t>, dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, n_rows, T, natural,
+                         row_group, keys_in, rows_in, cnt);
+      DISCO_CHECK_LAUNCH();
+      DISCO_HIP_TRY(rocprim::radix_sort_pairs(tmp, sort_tmp, (const uint64_t*)keys_in, keys_out, (const uint32_t*)rows_in,
+                                              perm, (size_t)n_rows, 0, 41, stream));
+    } else {
+      uint8_t* keys_in = reinterpret_cast<uint8_t*>(ws + L.off_keys_in);
+      uint8_t* keys_out = reinterpret_cast<uint8_t*>(ws + L.off_keys_out);
+      hipLaunchKernelGGL(k_row_keys<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, n_rows, T, natural,
+                         (const uint32_t*)nullptr, keys_in, rows_in, cnt);
+      DISCO_CHECK_LAUNCH();
+      DISCO_HIP_TRY(rocprim::radix_sort_pairs(tmp, sort_tmp, (const uint8_t*)keys_in, keys_out, (const uint32_t*)rows_in,
+                                              perm, (size_t)n_rows, 0, 8, stream));
+    }
   }
-  size_t sort_tmp = L.sort_tmp;
-  DISCO_HIP_TRY(rocprim::radix_sort_pairs(tmp, sort_tmp, (const uint8_t*)keys_in, keys_out, (const uint32_t*)rows_in,
-                                          perm, (size_t)n_rows, 0, 8, stream));
   if (L.n_hub_max > 0) {
     int64_t* pieces = reinterpret_cast<int64_t*>(ws + L.off_cntarr);
     int64_t* a = reinterpret_cast<int64_t*>(ws + L.off_scan_a);

@@ -108,10 +108,14 @@ __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ r
   const int wave = threadIdx.x >> 6;
   const int gl = lane % G;
   // XCD-aware block order (speed only): workgroups are dealt round-robin over the 8 XCDs, so workgroup b and
-  // b + 8 share an L2.  With xcd_chunk > 0 the workgroups of one XCD walk ONE contiguous eighth of the row order
-  // (consecutive rows of a locality-grouped order share neighbours: their gathers hit that XCD's L2).
+  // b + 8 share an L2.  With xcd_chunk > 0 the row order is cut into runs of xcd_chunk blocks and the runs are dealt
+  // to the XCDs in turn: the workgroups of one XCD walk a run of CONSECUTIVE rows (rows of a locality-grouped order
+  // share neighbours: their gathers hit that XCD's L2) while all eight stay in the same region of the order.
   int64_t bid = blockIdx.x;
-  if (xcd_chunk > 0) bid = (int64_t)(blockIdx.x & 7) * xcd_chunk + (blockIdx.x >> 3);
+  if (xcd_chunk > 0) {
+    const uint32_t q = blockIdx.x >> 3, c = (uint32_t)xcd_chunk;
+    bid = ((int64_t)(q / c) * 8 + (blockIdx.x & 7)) * c + q % c;
+  }
   int64_t grp = (bid * 4 + wave) * RPW + lane / G;
   if (grp >= count) return;
   int64_t row = perm ? (int64_t)perm[first + grp] : first + grp;
@@ -693,7 +697,10 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
   if (count > 0 && !swept) {
     int64_t blocks = (count + 4 * RPW - 1) / (4 * RPW);
     int64_t xcd_chunk = 0;
-    if (tuning().xcd_map && blocks >= 64) { xcd_chunk = (blocks + 7) / 8; blocks = xcd_chunk * 8; }
+    if (tuning().xcd_map && blocks >= 64) {       // 1: one contiguous eighth per XCD; S > 1: runs of S blocks
+      xcd_chunk = tuning().xcd_map == 1 ? (blocks + 7) / 8 : std::min<int64_t>(tuning().xcd_map, (blocks + 63) / 64);
+      blocks = (blocks + 8 * xcd_chunk - 1) / (8 * xcd_chunk) * (8 * xcd_chunk);
+    }
     if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
     hipLaunchKernelGGL((k_spmm_rows<VEC, G, NV, OP, HASVAL, A24>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
                        a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, mean, (int)a.F, xcd_chunk);

@@ -153,6 +153,7 @@ class SparseTensor:
         self._sweep_force: Optional[bool] = None   # sticky schedule(sweep=True/False) choice
         self._window_bytes: Optional[int] = None   # sticky schedule(window_bytes=) override
         self._hub_ws: Optional[torch.Tensor] = None    # partial-row workspace of the hub kernels (grown on demand)
+        self._row_groups: Optional[torch.Tensor] = None   # locality groups: major key of the row order
         self._t: Optional["SparseTensor"] = None
         self._shared = _StructCache()
         self.storage = _Storage(self)
@@ -243,6 +244,7 @@ class SparseTensor:
         out._sched_key, out._sched_auto = self._sched_key, self._sched_auto
         out._sweep, out._sweep_force, out._window_bytes = self._sweep, self._sweep_force, self._window_bytes
         out._shared = self._shared
+        out._row_groups = self._row_groups
         return out
 
     def fill_value(self, fill: float, dtype=torch.float32) -> "SparseTensor":
@@ -336,12 +338,20 @@ class SparseTensor:
             if key not in sh.sched:
                 n, nnz = self._sizes[0], self.nnz()
                 with torch.cuda.device(self.device):
-                    nbytes = lib.disco_schedule_workspace_bytes(n, nnz, hub_threshold, hub_piece)
-                    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
                     info = _lib.ScheduleInfo()
-                    _lib.check(lib.disco_schedule_build(_lib.ptr(self._rowptr), n, nnz, hub_threshold, hub_piece,
-                                                        _lib.ptr(ws), ws.numel(), info, _lib.current_stream(self.device)),
-                               "disco_schedule_build")
+                    if self._row_groups is not None:
+                        nbytes = lib.disco_schedule_grouped_workspace_bytes(n, nnz, hub_threshold, hub_piece)
+                        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+                        _lib.check(lib.disco_schedule_build_grouped(_lib.ptr(self._rowptr), n, nnz, hub_threshold, hub_piece,
+                                                                    _lib.ptr(self._row_groups), _lib.ptr(ws), ws.numel(), info,
+                                                                    _lib.current_stream(self.device)),
+                                   "disco_schedule_build_grouped")
+                    else:
+                        nbytes = lib.disco_schedule_workspace_bytes(n, nnz, hub_threshold, hub_piece)
+                        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+                        _lib.check(lib.disco_schedule_build(_lib.ptr(self._rowptr), n, nnz, hub_threshold, hub_piece,
+                                                            _lib.ptr(ws), ws.numel(), info, _lib.current_stream(self.device)),
+                                   "disco_schedule_build")
                     # keep only the part the SpMM kernels read
                     keep = int(info.off_multi_first + 8 * (info.n_multi_rows + 2))
                     keep = min(max(keep, 256), ws.numel())
@@ -389,12 +399,30 @@ class SparseTensor:
             self._sweep = None
         return ws, info
 
-    # ---- locality-aware row order (filled in below) -----------------------------------------------------------
-    def locality_groups(self, iters: int = 8) -> torch.Tensor:
-        raise NotImplementedError
+    # ---- locality-aware row order ----------------------------------------------------------------------------
+    def locality_groups(self, sweeps: int = 8, max_group: int = 0) -> torch.Tensor:
+        """Community label per node from ``disco_locality_labels`` (device-side label propagation, square graphs).
+        ``max_group`` > 0 bounds the size of a group (choose it so that a group's rows of x fit one XCD's L2)."""
+        assert self.device.type == "cuda" and self._sizes[0] == self._sizes[1], "locality pass: square graph on the GPU"
+        lib = _lib.load()
+        n = self._sizes[0]
+        labels = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = torch.empty(max(int(lib.disco_locality_workspace_bytes(n)), 256), dtype=torch.uint8, device=self.device)
+            _lib.check(lib.disco_locality_labels(_lib.ptr(self._rowptr), _lib.ptr(self._col32), n, int(sweeps), int(max_group), _lib.ptr(labels),
+                                                 _lib.ptr(ws), ws.numel(), _lib.current_stream(self.device)), "disco_locality_labels")
+        return labels[:n]
 
     def set_row_groups(self, groups: Optional[torch.Tensor]) -> None:
-        raise NotImplementedError
+        """Process rows group by group (``disco_schedule_build_grouped``); None returns to the degree-binned order.
+        Results do not change by a bit: only the order in which rows are processed does."""
+        if groups is not None:
+            assert groups.numel() == self._sizes[0] and groups.device == self.device
+            groups = groups.to(torch.int32).contiguous()
+        self._row_groups = groups
+        self._sched, self._sweep = None, None
+        old, self._shared = self._shared, _StructCache()          # schedules are per row order; the transpose is not
+        self._shared.t_struct, self._shared.t_perm = old.t_struct, old.t_perm
 
     def sweep_pays(self, feat: int = WIN_COLS) -> bool:
         """L2-blocked (windowed) propagation re-reads and re-writes the output block once per window, so it

@@ -86,6 +86,26 @@ int disco_schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz,
                          int64_t hub_threshold, int64_t hub_piece, void* sched_ws,
                          size_t sched_ws_bytes, disco_schedule_info* info_host, void* stream);
 
+/* Locality-grouped variant: `row_group` (uint32 per row, device) is the major sort key of the row order -- rows of one
+ * group are processed together, heavier rows first inside a group; hub rows are split as before.  With
+ * disco_set_tuning("xcd_map", 1) the workgroups of one XCD walk one contiguous eighth of that order, so the rows of
+ * a group gather through ONE L2.  Only the order of processing changes: results are bit-identical.
+ * disco_locality_labels computes such groups on the device: `sweeps` rounds of label propagation over the graph
+ * (square CSR; every node takes the most frequent label among its neighbours and itself, ties to the smaller
+ * label).  max_group = 0: plain propagation, deterministic (on graphs with hubs one label tends to swallow most
+ * rows); max_group > 0: no group grows beyond max_group rows (choose it so that a group's rows of x fit one XCD's
+ * 4 MiB L2) -- which rows take the last places of a group is then not reproducible from run to run.
+ * labels uint32[n_rows]; workspace from disco_locality_workspace_bytes.  Nothing synchronises.
+ * No counterpart in the reference (pymetis is pinned in /root/reference/requirements.txt:95 and never used). */
+size_t disco_schedule_grouped_workspace_bytes(int64_t n_rows, int64_t nnz, int64_t hub_threshold,
+                                              int64_t hub_piece);
+int disco_schedule_build_grouped(const int64_t* rowptr, int64_t n_rows, int64_t nnz, int64_t hub_threshold,
+                                 int64_t hub_piece, const uint32_t* row_group, void* sched_ws,
+                                 size_t sched_ws_bytes, disco_schedule_info* info_host, void* stream);
+size_t disco_locality_workspace_bytes(int64_t n_rows);
+int disco_locality_labels(const int64_t* rowptr, const int32_t* col, int64_t n_rows, int sweeps, int64_t max_group,
+                          uint32_t* labels, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- L2 window table (optional, for graphs whose rows re-use source rows heavily) ------------------
  * Cuts the source rows (columns) into windows of `window_rows` rows sized for the XCD's 4 MiB L2 and records,
  * per window and row of the schedule, where the row's entries of that window start (absolute uint32 offsets,
