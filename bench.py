@@ -18,8 +18,8 @@ variants of the generators (graphgen.py) -- see DESIGN.md section 4.
 
 Prints the JSON line on rank 0 (contract in the task statement): value = edges*feat/s of the whole job, plus
 `roofline` (dominant kernel, live HIP-event timing) and `cpu_baseline` (N=1 only: the oracle's OpenMP C port and
-BASELINE.md's two torch forms, on a bounded sample).  When extras are run the headline-only line is printed
-first and the complete line last, so that a failure inside an extra cannot lose the headline.
+BASELINE.md's two torch forms, on a bounded sample).  Exactly one line is printed; a watchdog prints it with what
+has been measured if the extra workloads overrun their budget, so that nothing inside an extra can lose the headline.
 """
 from __future__ import annotations
 
@@ -198,8 +198,8 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
         x = graphgen.features(n_local, F, spec.seed, device=dev, ld=ld)
         bufs = [torch.empty((n_local, ld), dtype=torch.float32, device=dev)[:, :F] for _ in range(min(K, 3))]
         order = args.order
-        if order == "auto":
-            order = "degree"
+        if order == "auto":         # community structure present: let the locality pass find it; else degree bins
+            order = "locality" if graph.startswith("community") else "degree"
         if order == "locality":
             torch.cuda.synchronize()
             t0 = time.time()
@@ -311,7 +311,7 @@ def cpu_baselines(adj, x, F, args):
       scatter   BASELINE.md section 2 "scatter form": index_select -> mul -> index_add_  (PyG's non-fused route)"""
     from oracle import c_oracle
     n_local, nnz = adj.size(0), adj.nnz()
-    rows = args.cpu_sample_rows or max(256, min(n_local, int(1.0e10 / max(1.0, nnz / n_local * F))))
+    rows = args.cpu_sample_rows or max(256, min(n_local, int(6.0e10 / max(1.0, nnz / n_local * F))))
     rows = min(rows, n_local)
     rp_t = adj._rowptr[: rows + 1].cpu()
     e_end = int(rp_t[-1])
@@ -423,8 +423,20 @@ def main():
             plan += [("scorer", "")]
         if world == 8 or args.extras == "all":
             plan += [("papers100M", "community"), ("papers100M", "config")] if world > 1 else []
-        if rank0(ctx):
-            print(json.dumps(out), flush=True)      # headline first: nothing below can lose it
+        # ONE JSON line is printed, at the end.  The extra workloads must not be able to lose the headline: if they
+        # overrun their budget by two minutes (a hung collective, a rank that died), rank 0 prints the line with what
+        # it has and every rank leaves.
+        import threading
+
+        def give_up():
+            if rank0(ctx):
+                out["extra_workloads"] = extras + [{"aborted": "extra workloads overran their time budget"}]
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(max(1.0, args.extras_budget_s + 120.0 - (time.time() - t_start)) + (0 if rank0(ctx) else 5), give_up)
+        watchdog.daemon = True
+        watchdog.start()
         for name, graph in plan:
             go = 1 if time.time() - t_start < args.extras_budget_s else 0
             if world > 1:       # rank 0 decides for everybody
@@ -435,12 +447,20 @@ def main():
                 extras.append({"workload": f"{name} ({graph})", "skipped": "time budget"})
                 continue
             torch.cuda.empty_cache()
-            if name == "scorer":
-                r = run_scorer(ctx, max(1, min(args.steps, 3)), 1)
-            else:
-                r = run_spmm(ctx, name, graph, args.steps, args.warmup)
-                r["unit"] = "edges*feat/s"
+            try:
+                if name == "scorer":
+                    r = run_scorer(ctx, max(1, min(args.steps, 3)), 1)
+                else:
+                    r = run_spmm(ctx, name, graph, args.steps, args.warmup)
+                    r["unit"] = "edges*feat/s"
+            except Exception as e:       # reported, never hidden; at N > 1 the other ranks meet the watchdog
+                r = {"workload": f"{name} ({graph})", "failed": f"{type(e).__name__}: {e}"[:400]}
+                extras.append(r)
+                if world > 1:
+                    break
+                continue
             extras.append(r)
+        watchdog.cancel()
         out["extra_workloads"] = extras
     if rank0(ctx):
         print(json.dumps(out), flush=True)

@@ -88,8 +88,8 @@ __device__ __forceinline__ void accumulate_range(int64_t beg, int64_t end, const
     int cv = 0;
     float wv = 0.0f;
     if (gl < n) {
-      cv = col[base + gl];
-      if constexpr (HASVAL) wv = val[base + gl];
+      cv = ld_entries(col + base + gl);
+      if constexpr (HASVAL) wv = ld_entries(val + base + gl);
     }
     consume_batch<VEC, G, NV, OP, HASVAL, A24>(cv, wv, n, x, ldx, off, acc);
   }
@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ r
 // in CSR order: the only difference to k_spmm_rows is that the running sum passes through memory (no
 // rounding: float32 in, float32 out) -- same bits.
 // TAIL: the column block's width is not a multiple of VEC, the last vector is stored masked (costs three registers:
-// that variant runs at 5 instead of 6 waves per SIMD rather than spilling).
+// that variant runs at 5 instead of 6 waves per SIMD rather than spilling).  !TAIL: write-through (`sc1`) stores of
+// the partial sums through a buffer descriptor on y (DISCO_WIN_YSTORE in disco_spmm_common.h; y block < 4 GiB).
 template <int VEC, int G, int NV, int OP, bool HASVAL, bool A24, bool TAIL>
 __global__ __launch_bounds__(256, NV == 1 ? (TAIL ? 5 : 6) : 1) void k_spmm_rows_win(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                        const float* __restrict__ val, const float* __restrict__ x,
@@ -195,15 +196,18 @@ __global__ __launch_bounds__(256, NV == 1 ? (TAIL ? 5 : 6) : 1) void k_spmm_rows
     const uint32_t len = e - b;
     cv = 0; wv = 0.0f;
     if ((uint32_t)gl < len) {
-      cv = col[(int64_t)b + gl];
-      if constexpr (HASVAL) wv = val[(int64_t)b + gl];
+      cv = ld_entries(col + (int64_t)b + gl);
+      if constexpr (HASVAL) wv = ld_entries(val + (int64_t)b + gl);
     }
     const float* yr = y + (int64_t)r * ldy;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       int idx = gl + G * v;
       vinit<VEC, OP>(yv[v]);
-      if (resume && idx < nvec) yv[v] = *reinterpret_cast<const V*>(yr + (int64_t)idx * VEC);
+      if (resume && idx < nvec) {
+        if constexpr (DISCO_WIN_YLOAD != 0) yv[v] = __builtin_nontemporal_load(reinterpret_cast<const V*>(yr + (int64_t)idx * VEC));
+        else yv[v] = *reinterpret_cast<const V*>(yr + (int64_t)idx * VEC);
+      }
     }
   };
   fetch(mb[0], me[0], mrow[0], cv_n, wv_n, y_n);
@@ -236,7 +240,15 @@ __global__ __launch_bounds__(256, NV == 1 ? (TAIL ? 5 : 6) : 1) void k_spmm_rows
             V a = acc[v];
             if (cnt > 0.0f) a = vdiv<VEC>(a, cnt);
             if (empty_row) a = 0.0f;
-            store_vec<VEC>(yr + (int64_t)idx * VEC, a, idx, nvec, TAIL ? ((flags >> 8) & (VEC - 1)) : 0);
+            if constexpr (!TAIL && VEC == 4 && DISCO_WIN_YSTORE == 2) {
+              typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+              const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, 0xffffffff, 0x27000);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, a), rs, (int)(uint32_t)((row * ldy + (int64_t)idx * VEC) * 4), 0, 16);
+            } else if constexpr (!TAIL && DISCO_WIN_YSTORE == 1) {
+              __builtin_nontemporal_store(a, reinterpret_cast<V*>(yr + (int64_t)idx * VEC));
+            } else {
+              store_vec<VEC>(yr + (int64_t)idx * VEC, a, idx, nvec, TAIL ? ((flags >> 8) & (VEC - 1)) : 0);
+            }
           }
         }
       }
@@ -667,7 +679,9 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       if (rpg > 2) rpg = 2;
       int64_t blocks = (count + 4 * RPW * rpg - 1) / (4 * RPW * rpg);
       if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
-      const bool tail = (a.F % VEC) != 0;
+      // the variant without a masked tail stores through a buffer descriptor on y (32-bit offsets, `sc1`): a y block of
+      // 4 GiB or more takes the other variant, whose stores are plain and whose tail count may be 0
+      const bool tail = (a.F % VEC) != 0 || (uint64_t)s.n_rows * (uint64_t)a.ldy * 4u >= (1ull << 32);
       for (int w = 0; w < P; ++w) {
         if (tail)
           hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, OP, HASVAL, A24, true>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,

@@ -30,6 +30,25 @@ template <> struct Vec<4> { typedef f4 type; };
 #define DISCO_U45 2
 #endif
 
+// Cache policy of the windowed kernel's streams (compile-time; measured in profiles/r2/win_cache_policy.log, Reddit):
+//   DISCO_WIN_YSTORE 2 (default): partial sums are stored with `buffer_store_dwordx4 ... sc1` -- write-through, the
+//     line leaves the XCD's L2 instead of displacing rows of x that the next gathers would hit: -6 % time.
+//     1: `nt` stores (no gain).  0: plain.  (`sc0 sc1` stores, what a volatile store compiles to, gave nothing.)
+//   DISCO_WIN_YLOAD 1: partial-sum loads carry `nt`; DISCO_CSR_NT 1: (col, val) loads carry `nt` (both: no gain).
+#ifndef DISCO_WIN_YLOAD
+#define DISCO_WIN_YLOAD 0
+#endif
+#ifndef DISCO_WIN_YSTORE
+#define DISCO_WIN_YSTORE 2
+#endif
+#ifndef DISCO_CSR_NT
+#define DISCO_CSR_NT 0
+#endif
+
+template <class T> __device__ __forceinline__ T ld_entries(const T* p) {
+  if constexpr (DISCO_CSR_NT != 0) return __builtin_nontemporal_load(p); else return *p;
+}
+
 template <int NV> struct Unroll { static constexpr int value = NV == 1 ? DISCO_U1 : NV == 2 ? DISCO_U2 : NV == 3 ? DISCO_U3 : DISCO_U45; };
 
 constexpr int OP_SUM = 0;

@@ -179,3 +179,56 @@ def test_max_message_passing_and_sampled_inference():
     with torch.no_grad():
         full = model.predict(x, adj)
     assert torch.allclose(out, full[:50], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("model_name", ["GCN", "SGC", "GraphSAGE"])
+def test_large_inference_batches_equal_full_graph_predict(model_name):
+    """basicgnn_large.py:283-318: batch-wise evaluation over per-layer bipartite adjacencies.  With loaders that hand
+    over every neighbour (layer 1: all rows, layer 2: the batch's rows) the batches must reproduce `predict` on the
+    resident graph."""
+    from collections import namedtuple
+    from disco_amd import SparseTensor
+    from disco_amd.models import basicgnn_large as M
+    torch.manual_seed(3)
+    n, d, C = 320, 20, 4
+    rowptr, col, val = make_graph(n, seed=11)
+    if model_name == "GraphSAGE":
+        val = None
+    adj = to_adj(rowptr, col, val, n)
+    x = torch.randn(n, d, device=DEV)
+    if model_name == "SGC":
+        model = M.SGC(nfeat=d, nhid=16, nclass=C, nlayers=2, sgc=True)
+    else:
+        model = getattr(M, model_name)(nfeat=d, nhid=16, nclass=C, nlayers=2, norm="BatchNorm")
+    model = model.to(DEV)
+    model.initialize()
+    Adj = namedtuple("Adj", ["adj_t", "e_id", "size"])
+
+    def rows(lo, hi):      # bipartite block: targets [lo, hi) first, every node as a source
+        rp = rowptr[lo:hi + 1] - rowptr[lo]
+        sl = slice(rowptr[lo], rowptr[hi])
+        return SparseTensor(rowptr=torch.from_numpy(rp.copy()).to(DEV), col=torch.from_numpy(col[sl].copy()).to(DEV),
+                            value=None if val is None else torch.from_numpy(val[sl].copy()).to(DEV),
+                            sparse_sizes=(hi - lo, n), is_sorted=True)
+
+    loader = []
+    for lo, hi in ((0, 40), (40, 100), (100, 101)):
+        # node order of a batch: its targets first (NeighborSampler's convention), then everybody else
+        n_id = torch.cat([torch.arange(lo, hi), torch.arange(0, lo), torch.arange(hi, n)])
+        inv = torch.empty(n, dtype=torch.long)
+        inv[n_id] = torch.arange(n)
+        # relabel the graph into the batch's node order
+        r, c = csr_to_coo(rowptr, col)
+        rr, cc = inv[torch.from_numpy(r)], inv[torch.from_numpy(c)]
+        full = SparseTensor(row=rr.to(DEV), col=cc.to(DEV), value=None if val is None else torch.from_numpy(val).to(DEV),
+                            sparse_sizes=(n, n))
+        rp_f, col_f, val_f = full.csr()
+        m = hi - lo
+        last = SparseTensor(rowptr=rp_f[:m + 1].clone(), col=col_f[:int(rp_f[m])].clone(),
+                            value=None if val_f is None else val_f[:int(rp_f[m])].clone(), sparse_sizes=(m, n), is_sorted=True)
+        loader.append((m, n_id, [Adj(full, None, (n, n)), Adj(last, None, (n, m))]))
+    out = model.large_inference(x.cpu(), loader, DEV)
+    with torch.no_grad():
+        ref = model.predict(x, adj)
+    assert out.shape == (101, C)
+    assert torch.allclose(out.to(DEV), ref[:101], rtol=2e-4, atol=2e-5)

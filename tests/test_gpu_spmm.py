@@ -374,6 +374,27 @@ def test_multi_window_resume_same_bits_as_plain(reduce):
     assert torch.equal(y_p, y_w)
 
 
+def test_windowed_path_with_output_block_beyond_4gib():
+    """The windowed kernel's write-through stores address y with 32-bit offsets; an output whose rows span 4 GiB or
+    more must take the plain-store variant -- same bits either way."""
+    from disco_amd import ops
+    n, F, ld = 280_000, 64, 4096                       # 280 000 rows x 16 KiB pitch = 4.6 GB
+    rowptr, col, val = random_csr(n, n, 6, seed=13, weighted=True)
+    x = torch.from_numpy(np.random.default_rng(3).standard_normal((n, F)).astype(np.float32)).to(dev())
+    small = to_adj(rowptr, col, val, n)
+    small.schedule(feat=F, sweep=True, window_bytes=50_000 * 4 * F)
+    y_small = ops.spmm_raw(small, x, "sum").clone()
+    big = torch.full((n, ld), 3.0, device=dev())
+    adj = to_adj(rowptr, col, val, n)
+    _, info = adj.schedule(feat=F, sweep=True, window_bytes=50_000 * 4 * F)
+    assert info.sweep_windows >= 5
+    y = ops.spmm_raw(adj, x, "sum", out=big[:, :F])
+    assert y.data_ptr() == big.data_ptr() and torch.equal(y, y_small)
+    assert bool((big[::977, F:] == 3.0).all())
+    y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x.cpu().numpy(), want_bound=True)
+    assert_fwd_close(y_small.cpu().numpy(), y64, bound)
+
+
 def test_set_value_copies_do_not_share_schedule_state():
     """A set_value copy that attaches a window table for another feature width (and is then freed) must leave
     its parent's schedule untouched: every object owns its host-side schedule info."""
