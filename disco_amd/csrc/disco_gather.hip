@@ -36,9 +36,44 @@ __global__ void k_pair_gather(const float* __restrict__ Z, int64_t n, int64_t ld
   *reinterpret_cast<V*>(out + p * ldo + (int64_t)rem * VW) = v;
 }
 
+// out[i, :] = x[idx[i], :] -- the send buffer of the halo exchange (rows of X that peers asked for, dist.py).
+// One lane per 16/8/4-byte vector, consecutive lanes along a row: coalesced on both sides; 2 * width * 4 bytes per
+// row, HBM bound.  Ids are the owner's local ids, validated when the partition is built.
+template <typename V>
+__global__ void k_gather_rows(const float* __restrict__ x, int64_t ldx, int wv, const int64_t* __restrict__ idx, int64_t n_idx,
+                              float* __restrict__ out, int64_t ldo) {
+  constexpr int VW = sizeof(V) / 4;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_idx * wv) return;
+  const int64_t i = t / wv;
+  const int k = (int)(t - i * wv);
+  *reinterpret_cast<V*>(out + i * ldo + (int64_t)k * VW) = *reinterpret_cast<const V*>(x + idx[i] * ldx + (int64_t)k * VW);
+}
+
 }  // namespace disco
 
 using namespace disco;
+
+extern "C" int disco_gather_rows_f32(const float* x, int64_t ldx, int64_t width, const int64_t* idx, int64_t n_idx, float* out,
+                                     int64_t ldo, void* stream_) {
+  if (width < 0 || n_idx < 0 || ldx < width || ldo < width) return DISCO_EINVAL;
+  if (n_idx == 0 || width == 0) return DISCO_OK;
+  if (!x || !idx || !out) return DISCO_EINVAL;
+  auto aligned = [&](int a) {
+    return width % a == 0 && ldx % a == 0 && ldo % a == 0 && (reinterpret_cast<uintptr_t>(x) % (4 * a)) == 0 &&
+           (reinterpret_cast<uintptr_t>(out) % (4 * a)) == 0;
+  };
+  const int vw = aligned(4) ? 4 : aligned(2) ? 2 : 1;
+  const int64_t wv = width / vw;
+  const int64_t blocks = (n_idx * wv + 255) / 256;
+  if (blocks > 0x7fffffffLL || wv > 0x3fffffff) return DISCO_EUNSUPPORTED;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (vw == 4) hipLaunchKernelGGL(k_gather_rows<float4>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, (int)wv, idx, n_idx, out, ldo);
+  else if (vw == 2) hipLaunchKernelGGL(k_gather_rows<float2>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, (int)wv, idx, n_idx, out, ldo);
+  else hipLaunchKernelGGL(k_gather_rows<float>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, (int)wv, idx, n_idx, out, ldo);
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}
 
 extern "C" int disco_pair_gather_f32(const float* Z, int64_t n, int64_t ldz, int64_t width, const int64_t* sel,
                                      const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_pairs, float* out,

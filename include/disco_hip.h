@@ -312,6 +312,13 @@ int disco_pair_gather_f32(const float* Z, int64_t n, int64_t ldz, int64_t width,
                           const int64_t* dst, int64_t n_edges, int64_t n_pairs, float* out, int64_t ldo, int* err_flag,
                           void* stream);
 
+/* Row gather for the halo exchange of the row-partitioned propagation: out[i, 0:width] = x[idx[i], 0:width],
+ * i < n_idx; x [*, ldx], out [n_idx, ldo].  The rows peers asked for go into the send buffer of the all-to-all
+ * (disco_amd/dist.py); idx must hold valid row ids of x (checked once when the partition is built).  No counterpart in
+ * the reference (single-GPU; `--parallel_gpu_ids` is parsed and never used, /root/reference/LargeScaleCondensing.py:31). */
+int disco_gather_rows_f32(const float* x, int64_t ldx, int64_t width, const int64_t* idx, int64_t n_idx, float* out,
+                          int64_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
