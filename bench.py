@@ -212,9 +212,6 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
                                     "edges_inside_a_group": round(float((groups[r] == groups[c]).float().mean()), 4)}
             del r, c
             adj.set_row_groups(groups)
-            if "xcd_map" not in args.tune:      # runs of 128 workgroups of the grouped order per XCD (reset below)
-                _lib.check(lib.disco_set_tuning(b"xcd_map", 128), "disco_set_tuning(xcd_map)")
-                cfg["xcd_map"] = 128
         ws, info = adj.schedule(args.hub_threshold, args.hub_piece, feat=F, sweep={"auto": None, "on": True, "off": False}[args.sweep],
                                 window_bytes=(args.window_kb << 10) or None)
         sws_bytes = int(lib.disco_spmm_workspace_bytes(info, F))
@@ -238,7 +235,7 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
                 src = dst
 
         windows = int(info.sweep_windows) if info.sweep_ws else 0
-        cfg.update({"parallelism": "single", "row_order": order, "l2_windows": windows,
+        cfg.update({"parallelism": "single", "row_order": order, "l2_windows": windows, "xcd_run": int(info.xcd_run),
                     "schedule": {"hub_rows": int(info.n_hub_rows), "hub_pieces": int(info.n_hub_pieces),
                                  "max_row_nnz": int(info.max_row_nnz)}})
         kernel = (f"k_spmm_rows_win: one timed call = one hop = {windows} window launches x column blocks of <= 128 floats"
@@ -248,6 +245,12 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
         g = ddist.build_partitioned_graph(n_global, nnz_target, F, skew, spec.seed, spec.norm, world, rank, dev, ld,
                                           comm_size=comm, mu=mu, exchange=args.exchange, K=K)
         n_local, nnz, nnz_global = g.part.n_local, g.nnz_local, g.nnz_global
+        order = args.order
+        if order == "auto":
+            order = "locality" if graph.startswith("community") else "degree"
+        if order == "locality" and g.part.adj_int.nnz():    # interior block: square, local ids
+            g.part.adj_int.set_row_groups(g.part.adj_int.locality_groups(args.locality_sweeps, args.locality_max_group))
+        cfg["row_order"] = order
         g.part.adj_int.schedule(feat=F)
         if g.part.adj_halo.nnz():
             g.part.adj_halo.schedule(feat=F)
@@ -268,8 +271,6 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
     t_setup = time.time() - t_setup
 
     elapsed = ctx.timed(step, warmup, steps)
-    if cfg.get("xcd_map"):
-        _lib.check(lib.disco_set_tuning(b"xcd_map", 0), "disco_set_tuning(xcd_map)")
     durs_ms = [a.elapsed_time(b) for a, b in events]
     hop_ms = sum(durs_ms) / max(len(durs_ms), 1)
     algo = b_min_bytes(nnz, n_local, F)                      # this rank's share per hop

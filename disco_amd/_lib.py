@@ -24,7 +24,7 @@ class ScheduleInfo(C.Structure):
         "n_rows", "nnz", "hub_threshold", "hub_piece", "n_hub_rows", "n_hub_pieces", "n_hub_partials",
         "n_multi_rows", "max_row_nnz", "off_perm", "off_piece_row", "off_piece_begin", "off_piece_end",
         "off_piece_slot", "off_multi_row", "off_multi_first", "ws_bytes",
-        "sweep_windows", "sweep_window_rows", "sweep_count_padded", "sweep_n_cols")] + [("sweep_ws", C.c_void_p), ("n_cols", C.c_int64)]
+        "sweep_windows", "sweep_window_rows", "sweep_count_padded", "sweep_n_cols")] + [("sweep_ws", C.c_void_p), ("n_cols", C.c_int64), ("xcd_run", C.c_int64)]
 
 
 _SIGNATURES = {
@@ -121,7 +121,7 @@ def load(path: str | None = None):
             raise RuntimeError(f"{p} does not export {name}; rebuild the extension")
         fn.restype = res
         fn.argtypes = args
-    if lib.disco_abi_version() != 1:
+    if lib.disco_abi_version() != 2:
         raise RuntimeError("libdisco_hip.so ABI version mismatch")
     _check_single_hip_runtime()
     if path is None:

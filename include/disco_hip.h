@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DISCO_ABI_VERSION 1
+#define DISCO_ABI_VERSION 2
 
 enum disco_status {
   DISCO_OK = 0,
@@ -67,6 +67,12 @@ typedef struct disco_schedule_info {
    * n_cols * pitch < 4 GiB, the gathers use 24-bit multiply / 32-bit offset addressing (one VALU op per
    * gather instead of a 64-bit multiply).  0 = unknown: 64-bit addressing. */
   int64_t n_cols;
+  /* XCD-aware workgroup order of the row kernel (speed only, never results).  Workgroups are dealt to the 8 XCDs in
+   * turn; with xcd_run = S > 0 the row order is cut into runs of S workgroups and XCD j takes runs j, j + 8, ...: the
+   * workgroups that share an L2 walk CONSECUTIVE rows.  disco_schedule_build sets 0 (rows in degree order share
+   * nothing), disco_schedule_build_grouped sets 128 (rows of a locality group share their neighbours); the caller may
+   * change it.  disco_set_tuning("xcd_map", v >= 0) overrides it for every call (experiments). */
+  int64_t xcd_run;
 } disco_schedule_info;
 
 int disco_abi_version(void);
@@ -87,9 +93,9 @@ int disco_schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz,
                          size_t sched_ws_bytes, disco_schedule_info* info_host, void* stream);
 
 /* Locality-grouped variant: `row_group` (uint32 per row, device) is the major sort key of the row order -- rows of one
- * group are processed together, heavier rows first inside a group; hub rows are split as before.  With
- * disco_set_tuning("xcd_map", 1) the workgroups of one XCD walk one contiguous eighth of that order, so the rows of
- * a group gather through ONE L2.  Only the order of processing changes: results are bit-identical.
+ * group are processed together, heavier rows first inside a group; hub rows are split as before, and info->xcd_run
+ * is set so that the workgroups of one XCD walk consecutive rows: the rows of a group gather through ONE L2.
+ * Only the order of processing changes: results are bit-identical.
  * disco_locality_labels computes such groups on the device: `sweeps` rounds of label propagation over the graph
  * (square CSR; every node takes the most frequent label among its neighbours and itself, ties to the smaller
  * label).  max_group = 0: plain propagation, deterministic (on graphs with hubs one label tends to swallow most

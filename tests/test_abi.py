@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(so)
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/disco_hip.h but not exported"
-    assert lib.disco_abi_version() == 1
+    assert lib.disco_abi_version() == 2
     lib.disco_status_string.restype = ctypes.c_char_p
     assert lib.disco_status_string(0) == b"ok"
     assert lib.disco_status_string(-3) == b"workspace too small"

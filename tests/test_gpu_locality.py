@@ -64,7 +64,7 @@ def test_labels_recover_planted_communities():
 
 
 @pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
-@pytest.mark.parametrize("xcd_map", [0, 1, 16])
+@pytest.mark.parametrize("xcd_map", [-1, 0, 1, 16])
 def test_grouped_schedule_same_bits_as_degree_order(reduce, xcd_map):
     from disco_amd import _lib, ops
     n, F = 9000, 100
@@ -77,7 +77,7 @@ def test_grouped_schedule_same_bits_as_degree_order(reduce, xcd_map):
     groups = torch.from_numpy(np.random.default_rng(9).integers(0, 37, n).astype(np.int32)).to(dev())
     grp.set_row_groups(groups)
     ws, ig = grp.schedule(2048, 1024, feat=F, sweep=False)
-    assert ig.n_hub_rows == ib.n_hub_rows == 2
+    assert ig.n_hub_rows == ib.n_hub_rows == 2 and ig.xcd_run == 128 and ib.xcd_run == 0
     # the order is group-major: along perm, group ids never decrease; inside a group heavier rows come first
     nh = int(ig.n_hub_rows)
     allp = ws[int(ig.off_perm): int(ig.off_perm) + 4 * n].view(torch.int32).long()   # hub rows first, then the order
@@ -97,4 +97,4 @@ def test_grouped_schedule_same_bits_as_degree_order(reduce, xcd_map):
         grp.set_row_groups(None)
         assert torch.equal(ops.spmm_raw(grp, x, reduce), y_ref)
     finally:
-        _lib.check(lib.disco_set_tuning(b"xcd_map", 0), "xcd_map")
+        _lib.check(lib.disco_set_tuning(b"xcd_map", -1), "xcd_map")

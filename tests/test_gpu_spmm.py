@@ -29,7 +29,7 @@ def to_adj(rowptr, col, val, n_cols):
 def test_extension_is_loaded_from_tree():
     from disco_amd import _lib
     lib = _lib.load()
-    assert lib.disco_abi_version() == 1
+    assert lib.disco_abi_version() == 2
     maps = open("/proc/self/maps").read()
     assert "disco_amd/csrc/libdisco_hip.so" in maps
     assert len({l.split()[-1] for l in maps.splitlines() if "libamdhip64" in l}) == 1
