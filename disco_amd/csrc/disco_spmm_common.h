@@ -122,12 +122,22 @@ __device__ __forceinline__ void lane_offsets(int nvec, int gl, int64_t (&off)[NV
 template <int VEC, bool A24>
 __device__ __forceinline__ typename Vec<VEC>::type gather_vec(const float* __restrict__ x, int64_t ldx, int c, int64_t off) {
   typedef typename Vec<VEC>::type V;
+#if defined(DISCO_GATHER_NT)
+  // experiment: every gather carries `nt` (does the hint change what the L2 retains?  profiles/r2/gather_nt.log)
+  if constexpr (A24) {
+    const uint32_t bo = __umul24((uint32_t)c, (uint32_t)ldx * 4u) + (uint32_t)off * 4u;
+    return __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const char*>(x) + bo));
+  } else {
+    return __builtin_nontemporal_load(reinterpret_cast<const V*>(x + (int64_t)c * ldx + off));
+  }
+#else
   if constexpr (A24) {
     const uint32_t bo = __umul24((uint32_t)c, (uint32_t)ldx * 4u) + (uint32_t)off * 4u;
     return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(x) + bo);
   } else {
     return *reinterpret_cast<const V*>(x + (int64_t)c * ldx + off);
   }
+#endif
 }
 
 template <int VEC> __device__ __forceinline__ typename Vec<VEC>::type vdiv(typename Vec<VEC>::type a, float d) {
