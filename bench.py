@@ -198,8 +198,9 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
         x = graphgen.features(n_local, F, spec.seed, device=dev, ld=ld)
         bufs = [torch.empty((n_local, ld), dtype=torch.float32, device=dev)[:, :F] for _ in range(min(K, 3))]
         order = args.order
-        if order == "auto":         # community structure present: let the locality pass find it; else degree bins
-            order = "locality" if graph.startswith("community") else "degree"
+        if order == "auto":         # community structure present and no L2 windows: let the locality pass find it
+            windows_pay = args.sweep == "on" or (args.sweep == "auto" and adj.sweep_pays(F))
+            order = "locality" if graph.startswith("community") and not windows_pay else "degree"
         if order == "locality":
             torch.cuda.synchronize()
             t0 = time.time()
@@ -247,7 +248,7 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
         n_local, nnz, nnz_global = g.part.n_local, g.nnz_local, g.nnz_global
         order = args.order
         if order == "auto":
-            order = "locality" if graph.startswith("community") else "degree"
+            order = "locality" if graph.startswith("community") and not g.part.adj_int.sweep_pays(F) else "degree"
         if order == "locality" and g.part.adj_int.nnz():    # interior block: square, local ids
             g.part.adj_int.set_row_groups(g.part.adj_int.locality_groups(args.locality_sweeps, args.locality_max_group))
         cfg["row_order"] = order

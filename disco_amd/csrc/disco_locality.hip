@@ -4,8 +4,10 @@
 // community gather mostly the same source rows.  If they are processed together -- and, with the XCD-aware block
 // order, by the same XCD -- those gathers hit that XCD's 4 MiB L2 instead of crossing the fabric.  The ids a dataset
 // ships with need not reflect that structure, so this pass recovers it: label propagation (every node takes the most
-// frequent label among its neighbours and itself; semi-synchronous by id parity and double buffered, so the result
-// does not depend on scheduling), the final labels are the `row_group` key of disco_schedule_build_grouped.
+// frequent label among its neighbours and itself, ties to the label with the smaller hash -- never to the smaller id,
+// which on a graph whose ids follow its communities lets the low-numbered communities flood their neighbours;
+// semi-synchronous by id parity and double buffered, so the result does not depend on scheduling), the final labels
+// are the `row_group` key of disco_schedule_build_grouped.
 // Only the ORDER in which rows are processed changes: X, the column ids and every row's summation order stay as they
 // are, so results are bit-identical with and without it.  No counterpart in the reference (`pymetis` is pinned in
 // /root/reference/requirements.txt:95 but never used).
@@ -16,9 +18,11 @@
 
 namespace disco {
 
-constexpr int kLpaSlots = 256;          // distinct neighbour labels a row can tally (more: the row keeps its label)
+constexpr int kLpaSlots = 1024;         // distinct neighbour labels a row can tally; labels that find no slot are not counted
 constexpr int64_t kLpaMaxDeg = 4096;    // longer rows (hubs: connected to everything) keep their label
 constexpr uint32_t kLpaEmpty = 0xffffffffu;
+constexpr uint32_t kLpaHashMul = 2654435761u;   // odd: label -> label * mul (mod 2^32) is a bijection ...
+constexpr uint32_t kLpaHashInv = 244002641u;    // ... and this is its inverse (mul * inv == 1 mod 2^32)
 
 // CAPPED: `size[label]` (device, uint32 per label, maintained with atomics) bounds every group at `cap` members -- a
 // plain label propagation lets one label swallow most of a graph that has hubs.  A row that wants to join a full
@@ -45,30 +49,27 @@ __global__ __launch_bounds__(256) void k_lpa_step(const int64_t* __restrict__ ro
   for (int s = lane; s < kLpaSlots; s += 64) { k[s] = kLpaEmpty; c[s] = 0u; }
   bool overflow = false;
   auto tally = [&](uint32_t label) {
-    uint32_t slot = (label * 2654435761u) >> 24;                // 8 bits
-    for (int probes = 0; probes < kLpaSlots; ++probes) {
+    uint32_t slot = (label * kLpaHashMul) >> 22;                // 10 bits
+    for (int probes = 0; probes < 64; ++probes) {
       const uint32_t old = atomicCAS(&k[slot], kLpaEmpty, label);
       if (old == kLpaEmpty || old == label) { atomicAdd(&c[slot], 1u); return; }
       slot = (slot + 1) & (kLpaSlots - 1);
     }
-    overflow = true;                                             // the table holds kLpaSlots other labels already
+    overflow = true;                                             // crowded table: this neighbour's vote is dropped
   };
   if (lane == 0) tally(own);
   for (int64_t i = b + lane; i < e; i += 64) {
     const int64_t u = col[i];
     if (u != v && u < n) tally(in[u]);
   }
-  if (__ballot(overflow) != 0ull) {
-    if (lane == 0) out[v] = own;
-    return;
-  }
+  (void)overflow;   // a row with more distinct neighbour labels than slots decides on the votes that fitted
   uint32_t chosen = own;
   for (int attempt = 0; attempt < (CAPPED ? 3 : 1); ++attempt) {
-    // most frequent label, ties to the smaller label: max of (count, ~label)
+    // most frequent label, ties to the smaller hash (a bijection of the label): max of (count, ~hash)
     unsigned long long best = 0;
     for (int s = lane; s < kLpaSlots; s += 64) {
       if (k[s] != kLpaEmpty && c[s] != 0u) {
-        const unsigned long long cand = ((unsigned long long)c[s] << 32) | (unsigned long long)(~k[s]);
+        const unsigned long long cand = ((unsigned long long)c[s] << 32) | (unsigned long long)(~(k[s] * kLpaHashMul));
         best = cand > best ? cand : best;
       }
     }
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void k_lpa_step(const int64_t* __restrict__ ro
       best = other > best ? other : best;
     }
     if (best == 0) break;                                        // every choice was full: stay
-    const uint32_t want = ~(uint32_t)(best & 0xffffffffu);
+    const uint32_t want = (~(uint32_t)(best & 0xffffffffu)) * kLpaHashInv;
     if (!CAPPED || want == own) { chosen = want; break; }
     int ok = 0;
     if (lane == 0) {

@@ -805,6 +805,15 @@ int spmm_dispatch(const SpmmArgs& a0) {
       max_cols = ((a.F + nblk - 1) / nblk + 31) / 32 * 32;
     }
   }
+  else if (vec >= 2) {
+    // Group-major schedules (xcd_run > 0: an XCD walks the rows of one locality group): column blocks narrow enough that
+    // the x rows a group shares stay in that XCD's 4 MiB L2 (8192 rows x 128 floats = 4 MiB); `row_cols` overrides.
+    const int64_t cap = tuning().row_cols > 0 ? tuning().row_cols : (a.info && a.info->xcd_run > 0 && tuning().row_cols == 0 ? 128 : 0);
+    if (cap > 0 && a.F > cap + cap / 4) {
+      int64_t nblk = (a.F + cap - 1) / cap;
+      max_cols = ((a.F + nblk - 1) / nblk + 31) / 32 * 32;
+    }
+  }
   for (int64_t c0 = 0; c0 < a0.F; c0 += max_cols) {
     int64_t f = a0.F - c0 < max_cols ? a0.F - c0 : max_cols;
     a.x = a0.x + c0; a.y = a0.y + c0; a.F = f;

@@ -97,8 +97,8 @@ int disco_schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz,
  * is set so that the workgroups of one XCD walk consecutive rows: the rows of a group gather through ONE L2.
  * Only the order of processing changes: results are bit-identical.
  * disco_locality_labels computes such groups on the device: `sweeps` rounds of label propagation over the graph
- * (square CSR; every node takes the most frequent label among its neighbours and itself, ties to the smaller
- * label).  max_group = 0: plain propagation, deterministic (on graphs with hubs one label tends to swallow most
+ * (square CSR; every node takes the most frequent label among its neighbours and itself, ties to the label with the
+ * smaller hash; a row tallies up to 1024 distinct labels, rows above 4096 entries keep theirs).  max_group = 0: plain propagation, deterministic (on graphs with hubs one label tends to swallow most
  * rows); max_group > 0: no group grows beyond max_group rows (choose it so that a group's rows of x fit one XCD's
  * 4 MiB L2) -- which rows take the last places of a group is then not reproducible from run to run.
  * labels uint32[n_rows]; workspace from disco_locality_workspace_bytes.  Nothing synchronises.

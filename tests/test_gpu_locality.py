@@ -34,7 +34,8 @@ def _lpa_numpy(rowptr, col, n, sweeps):
                 continue
             labels = np.concatenate([[lab[v]], lab[nb]])
             vals, cnt = np.unique(labels, return_counts=True)
-            new[v] = vals[cnt == cnt.max()].min()
+            tied = vals[cnt == cnt.max()]
+            new[v] = tied[np.argmin((tied * 2654435761) % (1 << 32))]       # ties: the smaller hash of the label
         lab = new
     return lab
 
