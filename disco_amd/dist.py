@@ -177,19 +177,32 @@ class RowPartition:
                            group=self.group, async_op=True)
         return work, recv
 
+    @staticmethod
+    def _col_chunks(F: int, width: int = 128) -> List[tuple]:
+        """Balanced column chunks of at most ~``width`` floats, multiples of 32 (the kernels' own column blocks)."""
+        n = max(1, (F + width - 1) // width)
+        per = ((F + n - 1) // n + 31) // 32 * 32
+        return [(c0, min(c0 + per, F)) for c0 in range(0, F, per)]
+
     def _spmm_dense(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """All-gather of the X shards, pipelined by column chunk: chunk c + 1 is on the wire while the halo SpMM of
+        chunk c runs, so only the first chunk's transfer (and what the SpMMs cannot cover) is exposed.  Every output
+        column still gets interior first, halo second: the bits do not depend on the chunking."""
         F, n = x.shape[1], self.n_local
-        ld = self._xld(F)
-        if self._full_buf is None or self._full_buf.shape[1] != ld:
-            self._full_buf = torch.empty((self.world * self.per, ld), dtype=x.dtype, device=x.device)
-            self._mine_buf = torch.zeros((self.per, ld), dtype=x.dtype, device=x.device)
-        self._mine_buf[:n, :F].copy_(x)
-        work = _all_gather_into(self._full_buf.reshape(-1), self._mine_buf.reshape(-1), self.group, async_op=True)
-        self._spmm_call(self.adj_int, x, "sum", out)              # overlaps with the all-gather
-        if work is not None:
-            work.wait()
-        if self.adj_halo.nnz():
-            self._spmm_call(self.adj_halo, self._full_buf[:, :F], "sum_acc", out)
+        chunks = self._col_chunks(F)
+        if self._full_buf is None or self._full_buf[0].shape[1] != chunks[0][1] - chunks[0][0] or len(self._full_buf) != len(chunks):
+            self._full_buf = [torch.empty((self.world * self.per, self._xld(c1 - c0)), dtype=x.dtype, device=x.device) for c0, c1 in chunks]
+            self._mine_buf = [torch.zeros((self.per, self._xld(c1 - c0)), dtype=x.dtype, device=x.device) for c0, c1 in chunks]
+        works = []
+        for (c0, c1), full, mine in zip(chunks, self._full_buf, self._mine_buf):
+            mine[:n, :c1 - c0].copy_(x[:, c0:c1])
+            works.append(_all_gather_into(full.reshape(-1), mine.reshape(-1), self.group, async_op=True))
+        self._spmm_call(self.adj_int, x, "sum", out)              # overlaps with the transfers
+        for (c0, c1), full, work in zip(chunks, self._full_buf, works):
+            if work is not None:
+                work.wait()
+            if self.adj_halo.nnz():
+                self._spmm_call(self.adj_halo, full[:, :c1 - c0], "sum_acc", out[:, c0:c1])
         return out
 
     def spmm(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
@@ -208,7 +221,7 @@ class RowPartition:
         """Bytes this rank RECEIVES per hop."""
         ld = self._xld(F)
         if self.dense:
-            return (self.world - 1) * self.per * ld * 4
+            return (self.world - 1) * self.per * sum(self._xld(c1 - c0) for c0, c1 in self._col_chunks(F)) * 4
         return self.n_halo * ld * 4
 
 
