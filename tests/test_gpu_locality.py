@@ -99,3 +99,53 @@ def test_grouped_schedule_same_bits_as_degree_order(reduce, xcd_map):
         assert torch.equal(ops.spmm_raw(grp, x, reduce), y_ref)
     finally:
         _lib.check(lib.disco_set_tuning(b"xcd_map", -1), "xcd_map")
+
+
+def test_grouped_schedule_column_blocks_keep_the_bits_of_non_hub_rows():
+    """Under a group-major schedule wide operands are processed in column blocks of ~128 floats (so that a group's x
+    rows fit the XCD's L2).  Rows below the hub threshold sum in strict CSR order whatever the block width: same bits
+    as the one-pass degree order.  Hub rows group their partial sums by lane group and may move by rounding."""
+    from disco_amd import _lib, ops
+    from oracle import c_oracle
+    from helpers import assert_fwd_close
+    n, F = 6000, 300
+    rowptr, col, val = random_csr(n, n, 25, seed=5, hubs=[(9, 5000)], weighted=True)
+    x = torch.from_numpy(np.random.default_rng(2).standard_normal((n, F)).astype(np.float32)).to(dev())
+    base = _adj(rowptr, col, val, n)
+    base.schedule(2048, 1024, feat=F, sweep=False)
+    y_ref = ops.spmm_raw(base, x, "sum").clone()
+    grp = _adj(rowptr, col, val, n)
+    grp.set_row_groups(torch.arange(n, device=dev(), dtype=torch.int32) // 500)
+    _, ig = grp.schedule(2048, 1024, feat=F, sweep=False)
+    assert ig.xcd_run == 128
+    y = ops.spmm_raw(grp, x, "sum")
+    keep = torch.ones(n, dtype=torch.bool, device=dev())
+    keep[9] = False
+    assert torch.equal(y[keep], y_ref[keep])
+    y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x.cpu().numpy(), want_bound=True)
+    assert_fwd_close(y.cpu().numpy(), y64, bound)
+    lib = _lib.load()
+    _lib.check(lib.disco_set_tuning(b"row_cols", -1), "row_cols")        # one pass: the hub row agrees bit for bit as well
+    try:
+        assert torch.equal(ops.spmm_raw(grp, x, "sum"), y_ref)
+    finally:
+        _lib.check(lib.disco_set_tuning(b"row_cols", 0), "row_cols")
+
+
+def test_windows_are_skipped_when_ids_follow_the_communities():
+    """sweep_pays: dense enough for L2 windows, but with every row's entries inside its own id block a launch per
+    window would leave most lane groups idle -- the concentration test says no; the same graph behind a random
+    relabelling says yes."""
+    from disco_amd import SparseTensor
+    n, deg, block = 60_000, 400, 2000
+    g = torch.Generator(device="cpu").manual_seed(3)
+    row = torch.arange(n).repeat_interleave(deg)
+    inside = torch.rand(n * deg, generator=g) < 0.8
+    col = torch.where(inside, (row // block) * block + torch.randint(0, block, (n * deg,), generator=g),
+                      torch.randint(0, n, (n * deg,), generator=g))
+    perm = torch.randperm(n, generator=g)
+    ordered = SparseTensor(row=row.to(dev()), col=col.to(dev()), value=None, sparse_sizes=(n, n))
+    scrambled = SparseTensor(row=perm[row].to(dev()), col=perm[col].to(dev()), value=None, sparse_sizes=(n, n))
+    F = 602                                         # column blocks of 128 floats: a window is 11 264 source rows, 6 windows
+    assert ordered.window_concentration(11264) > 0.6 > 0.25 > scrambled.window_concentration(11264)
+    assert not ordered.sweep_pays(F) and scrambled.sweep_pays(F)
