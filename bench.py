@@ -53,6 +53,12 @@ def parse():
     ap.add_argument("--locality-sweeps", type=int, default=8, help="label-propagation sweeps of --order locality")
     ap.add_argument("--order", default="auto", choices=["auto", "degree", "locality"],
                     help="row schedule: degree-binned, or grouped by the device-side locality pass first")
+    ap.add_argument("--partition", default="auto", choices=["auto", "rows", "features"],
+                    help="N > 1: replicate the graph and split the feature columns (no exchange; auto when the graph fits one "
+                         "GPU), or 1-D row partition with halo exchange over RCCL")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="on ONE GPU: run rank 0's share of an N-rank feature-partition job (it has no exchange)")
+    ap.add_argument("--feat", type=int, default=0, help="override the feature width (experiments; reported in config)")
     ap.add_argument("--hops", type=int, default=2)
     ap.add_argument("--ld-pad", type=int, default=32, help="pad the feature leading dimension to this many floats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,26 +169,45 @@ def graph_params(name: str, args, world: int):
     return spec, n, nnz, ("weak" if world == 1 else "strong")
 
 
-def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu: bool = False):
+def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu: bool = False, partition: str = None):
     """Build one workload, time it, return the result dict (collective: every rank calls it)."""
     from disco_amd import SparseTensor, _lib, graphgen, utils
+    from disco_amd import dist as ddist
     args, dev, world, rank = ctx.args, ctx.dev, ctx.world, ctx.rank
+    # --emulate-world N on ONE GPU: do exactly what rank 0 of an N-rank feature-partition job does (that partition has
+    # no exchange, so a rank's time IS the job's time); reported as n_gpus = 1 with the emulation named in config
+    gworld, grank = (args.emulate_world, 0) if (world == 1 and args.emulate_world > 1) else (world, rank)
     lib = _lib.load()
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         _lib.check(lib.disco_set_tuning(k.encode(), int(v)), f"disco_set_tuning({k})")
-    spec, n_global, nnz_target, scaling = graph_params(name, args, world)
-    F, K = spec.feat, args.hops
+    spec, n_global, nnz_target, scaling = graph_params(name, args, gworld)
+    F, K = (args.feat or spec.feat), args.hops
     skew = spec.skew if args.skew is None else args.skew
+    partition = partition or args.partition
+    if gworld == 1:
+        partition = "single"
+    elif partition == "auto":
+        # Replicate the graph and split the FEATURE columns (no exchange at all) whenever the whole graph fits one GPU:
+        # generator temporaries + CSR ~ 48 B per entry, three column slabs of X; else split the rows (halo exchange).
+        need = nnz_target * 40 + 3 * n_global * ((F + gworld - 1) // gworld + 16) * 4
+        partition = "features" if need < 0.8 * torch.cuda.get_device_properties(dev).total_memory or world == 1 else "rows"
+    Fg = F                                  # global width; F below is what THIS rank propagates
+    if partition == "features":
+        c0, c1 = ddist.feature_slabs(Fg, gworld)[grank]
+        F = c1 - c0
+        assert F > 0, "more ranks than 4-float column groups"
     ld = (F + args.ld_pad - 1) // args.ld_pad * args.ld_pad
+    if partition == "features":
+        ld = (F + 15) // 16 * 16            # 64-byte rows: a narrow slab should not pay for padding it never reads
     comm, mu = (graphgen.COMMUNITY_SIZE, graphgen.COMMUNITY_MU) if graph.startswith("community") else (0, 1.0)
     events = []
     t_setup = time.time()
-    cfg = {"K": K, "F": F, "ld": ld, "skew": skew, "scale": args.scale,
+    cfg = {"K": K, "F": Fg, "ld": ld, "skew": skew, "scale": args.scale,
            "graph": {"config": "configuration model, no locality",
                      "community": f"LFR-style communities of {comm} nodes, mixing mu={mu}, partitioner order",
                      "community-scrambled": f"LFR-style communities of {comm} nodes, mixing mu={mu}, ids scrambled"}[graph]}
-    if world == 1:
+    if partition in ("single", "features"):
         row, col = graphgen.powerlaw_edges(n_global, nnz_target, skew, spec.seed, device=dev, comm_size=comm, mu=mu,
                                            scramble=graph.endswith("scrambled"))
         adj = SparseTensor(row=row, col=col, value=None, sparse_sizes=(n_global, n_global), is_sorted=True)
@@ -195,7 +220,7 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
             adj = adj.set_value(w)
             del r, c
         n_local, nnz, nnz_global = n_global, adj.nnz(), adj.nnz()
-        x = graphgen.features(n_local, F, spec.seed, device=dev, ld=ld)
+        x = graphgen.features(n_local, F, spec.seed + 31 * grank, device=dev, ld=ld)
         bufs = [torch.empty((n_local, ld), dtype=torch.float32, device=dev)[:, :F] for _ in range(min(K, 3))]
         order = args.order
         if order == "auto":         # community structure present and no L2 windows: let the locality pass find it
@@ -236,13 +261,15 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
                 src = dst
 
         windows = int(info.sweep_windows) if info.sweep_ws else 0
-        cfg.update({"parallelism": "single", "row_order": order, "l2_windows": windows, "xcd_run": int(info.xcd_run),
+        par = "single" if partition == "single" else (
+            f"feature partition x{gworld}: graph replicated on every rank, {F} of {Fg} columns per rank, no exchange" +
+            (f" [rank 0's share run alone on one GPU: --emulate-world {gworld}]" if world == 1 else ""))
+        cfg.update({"parallelism": par, "row_order": order, "l2_windows": windows, "xcd_run": int(info.xcd_run),
                     "schedule": {"hub_rows": int(info.n_hub_rows), "hub_pieces": int(info.n_hub_pieces),
                                  "max_row_nnz": int(info.max_row_nnz)}})
         kernel = (f"k_spmm_rows_win: one timed call = one hop = {windows} window launches x column blocks of <= 128 floats"
                   if windows else "k_spmm_rows (+ k_spmm_hub, same C-ABI call)")
     else:
-        from disco_amd import dist as ddist
         g = ddist.build_partitioned_graph(n_global, nnz_target, F, skew, spec.seed, spec.norm, world, rank, dev, ld,
                                           comm_size=comm, mu=mu, exchange=args.exchange, K=K)
         n_local, nnz, nnz_global = g.part.n_local, g.nnz_local, g.nnz_global
@@ -276,12 +303,14 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
     hop_ms = sum(durs_ms) / max(len(durs_ms), 1)
     algo = b_min_bytes(nnz, n_local, F)                      # this rank's share per hop
     achieved = algo / (hop_ms * 1e-3) / 1e9 if durs_ms else 0.0
-    value = float(K) * nnz_global * F * steps / elapsed
+    value = float(K) * nnz_global * Fg * steps / elapsed
+    if world == 1 and gworld > 1:
+        value /= gworld                   # one rank's share of the emulated job
     cfg.update({"nnz_per_rank": nnz, "rows_per_rank": n_local, "nnz_global": nnz_global, "setup_s": round(t_setup, 1)})
     res = {
         "value": value, "ms_per_step": elapsed / steps * 1e3, "scaling": scaling, "n_gpus": world,
         "workload": f"{spec.name}{' (1/8-size square stand-in)' if name == 'papers100M-shard' else ''} K={K} GCN-normalised "
-                    f"propagation, N={n_global}, nnz={nnz_global} (incl. self-loops), F={F}",
+                    f"propagation, N={n_global}, nnz={nnz_global} (incl. self-loops), F={Fg}",
         "config": cfg,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel,
@@ -291,7 +320,7 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
     }
     # HBM / fabric bytes per hop from the PMC passes committed under profiles/ for exactly this configuration
     # (bench.py cannot read hardware counters itself); null when no matching measurement exists.
-    if world == 1 and args.scale == 1.0:
+    if world == 1 and gworld == 1 and args.scale == 1.0 and not args.feat:
         try:
             with open(os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
@@ -301,7 +330,7 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
                 res["roofline"]["traffic_source"] = f"profiles/r2/pmc_traffic.json[{key}]"
         except (OSError, KeyError, ValueError):
             pass
-    if want_cpu and world == 1:
+    if want_cpu and world == 1 and gworld == 1:
         res["cpu_baseline"] = cpu_baselines(adj, x, F, args)
     return res
 
@@ -418,13 +447,18 @@ def main():
 
     extras = []
     if args.extras != "none" and args.workload == "reddit" and args.graph == "config":
-        plan = [("products", "config"), ("products", "community")]
+        # (workload, generator, partition); partition None = --partition (auto: feature columns when the graph fits)
+        plan = [("products", "config", None), ("products", "community", None)]
         if world > 1:
-            plan = [("reddit", "community")] + plan
+            plan = [("reddit", "community", None)] + plan
+            if world == 8 or args.extras == "all":
+                plan += [("papers100M", "config", None), ("papers100M", "community", None)]
+            # the 1-D row partition with halo exchange (north_star's design for graphs that exceed one GPU), for comparison
+            plan += [("products", "config", "rows"), ("products", "community", "rows"), ("reddit", "config", "rows")]
+            if world == 8 or args.extras == "all":
+                plan += [("papers100M", "community", "rows")]
         else:
-            plan += [("scorer", "")]
-        if world == 8 or args.extras == "all":
-            plan += [("papers100M", "community"), ("papers100M", "config")] if world > 1 else []
+            plan += [("scorer", "", None)]
         # ONE JSON line is printed, at the end.  The extra workloads must not be able to lose the headline: if they
         # overrun their budget by two minutes (a hung collective, a rank that died), rank 0 prints the line with what
         # it has and every rank leaves.
@@ -439,7 +473,7 @@ def main():
         watchdog = threading.Timer(max(1.0, args.extras_budget_s + 120.0 - (time.time() - t_start)) + (0 if rank0(ctx) else 5), give_up)
         watchdog.daemon = True
         watchdog.start()
-        for name, graph in plan:
+        for name, graph, part in plan:
             go = 1 if time.time() - t_start < args.extras_budget_s else 0
             if world > 1:       # rank 0 decides for everybody
                 flag = torch.tensor([go], dtype=torch.int64, device=ctx.dev if ctx.backend == "nccl" else "cpu")
@@ -453,7 +487,7 @@ def main():
                 if name == "scorer":
                     r = run_scorer(ctx, max(1, min(args.steps, 3)), 1)
                 else:
-                    r = run_spmm(ctx, name, graph, args.steps, args.warmup)
+                    r = run_spmm(ctx, name, graph, args.steps, args.warmup, partition=part)
                     r["unit"] = "edges*feat/s"
             except Exception as e:       # reported, never hidden; at N > 1 the other ranks meet the watchdog
                 r = {"workload": f"{name} ({graph})", "failed": f"{type(e).__name__}: {e}"[:400]}

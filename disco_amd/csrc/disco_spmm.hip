@@ -27,7 +27,7 @@ template <int VEC, int G, int NV, int OP, bool HASVAL, bool A24>
 __device__ __forceinline__ void consume_batch(int cv, float wv, int n, const float* __restrict__ x, int64_t ldx,
                                               const int64_t (&off)[NV], typename Vec<VEC>::type (&acc)[NV]) {
   typedef typename Vec<VEC>::type V;
-  constexpr int U = Unroll<NV>::value;
+  constexpr int U = Unroll<NV>::value < G ? Unroll<NV>::value : G;   // a batch holds at most G entries
   int j = 0;
   for (; j + U <= n; j += U) {
     V xr[U][NV];
@@ -636,7 +636,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       else if (rc != DISCO_EUNSUPPORTED) return rc;      // EUNSUPPORTED: shape outside the streaming kernel, fall through
     }
   }
-  if constexpr (OP == OP_SUM && VEC == 4 && NV == 1) {
+  if constexpr (OP == OP_SUM && VEC == 4 && NV == 1 && G >= 16) {
     if (!swept && count > 0 && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && tuning().sweep_mode == 3) {
       const disco_schedule_info& s = *a.info;
       const uint32_t* wptr = reinterpret_cast<const uint32_t*>(s.sweep_ws);
@@ -669,7 +669,7 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       }
     }
   }
-  if constexpr (VEC == 4 || VEC == 2) {
+  if constexpr ((VEC == 4 || VEC == 2) && G >= 16) {
     // windowed launches (L2-blocked): mean of an accumulating call is not meaningful, so SUM_ACC + MEAN never meet
     if (!swept && count > 0 && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && tuning().sweep_mode >= 2) {
       const disco_schedule_info& s = *a.info;
@@ -747,9 +747,15 @@ static int launch_vec(const SpmmArgs& a, int nvec) {
   const Tuning& t = tuning();
   int G, NV;
   if (t.force_g > 0 && t.force_nv > 0 && (int64_t)t.force_g * t.force_nv >= nvec) { G = t.force_g; NV = t.force_nv; }
+  else if (VEC == 4 && nvec <= 4 && t.narrow_groups) { G = 4; NV = 1; }     // rows of <= 64 B / <= 128 B: 16 / 8 rows per wave
+  else if (VEC == 4 && nvec <= 8 && t.narrow_groups) { G = 8; NV = 1; }     // (column slabs of the feature partition, dist.py)
   else if (nvec <= 16) { G = 16; NV = 1; }
   else if (nvec <= 32) { G = 32; NV = 1; }
   else { G = 64; NV = (nvec + 63) / 64; }
+  if constexpr (VEC == 4) {
+    if (G == 4 && NV == 1) return launch_op<VEC, 4, 1>(a, nvec);
+    if (G == 8 && NV == 1) return launch_op<VEC, 8, 1>(a, nvec);
+  }
   if (G == 16 && NV == 1) return launch_op<VEC, 16, 1>(a, nvec);
   if (G == 16 && NV == 2) return launch_op<VEC, 16, 2>(a, nvec);
   if (G == 32 && NV == 1) return launch_op<VEC, 32, 1>(a, nvec);

@@ -311,6 +311,69 @@ def build_partitioned_graph(n_global: int, nnz_global: int, F: int, skew: float,
     return PartitionedGraph(part, x, y, tmp, F, nnz_l, int(t.item()), n_global)
 
 
+def feature_slabs(F: int, world: int) -> List[tuple]:
+    """Column ranges [c0, c1) of the ``world`` feature slabs: contiguous, in units of 4 floats (128-bit gathers), as
+    equal as that allows; a rank may get an empty slab when F < 4 * world."""
+    nv = (F + 3) // 4
+    cuts = [min(F, 4 * (nv * g // world)) for g in range(world)] + [F]
+    return [(cuts[g], cuts[g + 1]) for g in range(world)]
+
+
+@dataclass
+class FeaturePartitionedGraph:
+    """Feature (column) partition of the K-hop propagation: EVERY rank holds the whole normalised graph -- a CSR of a
+    few GB against 288 GB of HBM -- and one column slab of X.  A^K X is independent per feature column, so the K hops
+    need NO exchange at all: xGMI moves tens of GB/s per link where HBM moves TB/s, and a row partition of a graph
+    without locality ships nearly the whole feature table every hop (papers100M-shaped at 8 ranks: 50 GB received
+    per rank and hop, ~10x the time of the SpMM itself).  What it costs: every rank streams the whole CSR (8 B per
+    entry and hop), and slabs narrower than 32 floats gather less than a 128-byte line per request.  No counterpart
+    in the reference (single GPU)."""
+    adj: SparseTensor
+    x: torch.Tensor
+    y: torch.Tensor
+    tmp: List[torch.Tensor]
+    cols: tuple
+    F: int
+    nnz_global: int
+    n_global: int
+
+    def khop(self, K: int, events=None):
+        from . import ops
+        src = self.x
+        for k in range(K):
+            dst = self.y if k == K - 1 else self.tmp[k & 1]
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if src.shape[1]:
+                ops.spmm_raw(self.adj, src, "sum", out=dst)
+            if events is not None:
+                e1.record()
+                events.append((e0, e1, src.shape[1]))
+            src = dst
+        return self.y
+
+    def describe(self):
+        return {"exchange": "none: the graph is replicated, every rank propagates its own feature columns",
+                "columns": list(self.cols), "csr_bytes_replicated": self.adj.nnz() * 8 + (self.n_global + 1) * 8}
+
+
+def build_feature_partitioned_graph(adj: SparseTensor, x_slab_fn: Callable, F: int, world: int, rank: int, K: int = 2,
+                                    ld_pad: int = 16) -> FeaturePartitionedGraph:
+    """Wrap the (replicated, already normalised) adjacency with this rank's column slab.  ``x_slab_fn(c0, c1, ld)`` returns
+    the [N, c1 - c0] slab of X as a column view of a buffer with leading dimension ``ld`` (from a loader, or synthetic)."""
+    c0, c1 = feature_slabs(F, world)[rank]
+    w = c1 - c0
+    ld = max(ld_pad, (w + ld_pad - 1) // ld_pad * ld_pad)
+    n = adj.size(0)
+    dev = adj.device
+    x = x_slab_fn(c0, c1, ld)
+    assert x.shape == (n, w)
+    y = torch.empty((n, ld), dtype=torch.float32, device=dev)[:, :w]
+    tmp = [torch.empty((n, ld), dtype=torch.float32, device=dev)[:, :w] for _ in range(min(max(K - 1, 0), 2))]
+    return FeaturePartitionedGraph(adj, x, y, tmp, (c0, c1), F, adj.nnz(), n)
+
+
 def sharded_edge_construction(pge_edge, Z: torch.Tensor, threshold: float, variant: str = "transductive", group=None):
     """``PGE_Edge.edge_construction`` over several GPUs (scorer row): the n x n pair grid is cut
     into row blocks, rank g scores rows [g*per, (g+1)*per) -- the n^2 x H x H GEMM, the only expensive part --

@@ -193,3 +193,48 @@ def test_global_graph_partition_on_the_gpu(comm, mu, K, tmp_path):
     # the halo is an outcome: about half of the entries without locality (dense exchange chosen), about mu / 2 with it
     assert (halo_frac > 0.4 and all(p["dense"] for p in parts)) if comm == 0 else halo_frac < 0.2, halo_frac
     assert len({p["dense"] for p in parts}) == 1
+
+
+def _feature_worker(rank, world, port, n, F, K, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disco_amd import SparseTensor
+        from disco_amd.dist import build_feature_partitioned_graph
+        dev = torch.device("cuda", 0)
+        rowptr, col, val = random_csr(n, n, 9, seed=78, hubs=[(3, 2600)], weighted=True)
+        x = torch.from_numpy(np.random.default_rng(6).standard_normal((n, F)).astype(np.float32)).to(dev)
+        adj = SparseTensor(rowptr=torch.from_numpy(rowptr).to(dev), col=torch.from_numpy(col).to(dev),
+                           value=torch.from_numpy(val).to(dev), sparse_sizes=(n, n), is_sorted=True)
+
+        def slab(c0, c1, ld):
+            buf = torch.zeros((n, ld), device=dev)
+            buf[:, :c1 - c0] = x[:, c0:c1]
+            return buf[:, :c1 - c0]
+
+        g = build_feature_partitioned_graph(adj, slab, F, world, rank, K=K)
+        y = g.khop(K)
+        torch.cuda.synchronize()
+        torch.save({"y": y.cpu(), "cols": g.cols}, os.path.join(result_dir, f"f{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("F,world,K", [(100, 2, 2), (13, 3, 3)])
+def test_feature_partition_matches_global_oracle(F, world, K, tmp_path):
+    """Feature (column) partition: the graph is replicated, every rank propagates its own column slab, nothing is
+    exchanged; the slabs put side by side are the K-hop result (slabs of 52/48 and 4/4/5 columns: 4- and 16-lane groups)."""
+    n = 3000
+    mp.spawn(_feature_worker, args=(world, _free_port(), n, F, K, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(tmp_path / f"f{r}.pt", weights_only=True) for r in range(world)]
+    cols = [tuple(p["cols"]) for p in parts]
+    assert cols[0][0] == 0 and cols[-1][1] == F and all(cols[i][1] == cols[i + 1][0] for i in range(world - 1))
+    got = np.concatenate([p["y"].numpy() for p in parts], axis=1)
+    rowptr, col, val = random_csr(n, n, 9, seed=78, hubs=[(3, 2600)], weighted=True)
+    x = np.random.default_rng(6).standard_normal((n, F)).astype(np.float32)
+    ref = orc.khop_csr(rowptr, col, val, x, K, np.float64)
+    bound = np.abs(x).astype(np.float64)
+    for _ in range(K):
+        bound = orc.spmm_abs_bound(rowptr, col, val, bound)
+    assert np.all(np.abs(got - ref) <= RTOL * K * bound + 1e-30)

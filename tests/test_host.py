@@ -163,3 +163,15 @@ def test_pge_edge_shell_contract():
     params = {k: v.numpy() for k, v in m.state_dict().items()}
     ref = orc.sigmoid(orc.pge_edge_logits(params, e.numpy(), np.float64))
     assert np.allclose(p.numpy(), ref, atol=2e-6)
+
+
+def test_feature_slabs_cover_the_columns_in_vector_units():
+    from disco_amd.dist import feature_slabs
+    for F, world in ((602, 8), (128, 8), (100, 8), (100, 3), (13, 3), (5, 4), (128, 1)):
+        slabs = feature_slabs(F, world)
+        assert len(slabs) == world and slabs[0][0] == 0 and slabs[-1][1] == F
+        assert all(a[1] == b[0] for a, b in zip(slabs, slabs[1:]))
+        assert all(c0 % 4 == 0 and c1 >= c0 for c0, c1 in slabs)
+        widths = [c1 - c0 for c0, c1 in slabs]
+        assert max(widths) - min(widths) <= 4 + (F % 4 != 0) * 3
+    assert feature_slabs(128, 8) == [(16 * g, 16 * g + 16) for g in range(8)]
