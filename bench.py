@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--partition", default="auto", choices=["auto", "rows", "features"],
                     help="N > 1: replicate the graph and split the feature columns (no exchange; auto when the graph fits one "
                          "GPU), or 1-D row partition with halo exchange over RCCL")
+    ap.add_argument("--slab-pad", type=int, default=16, help="feature partition: pad a slab's leading dimension to this many floats")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="on ONE GPU: run rank 0's share of an N-rank feature-partition job (it has no exchange)")
     ap.add_argument("--feat", type=int, default=0, help="override the feature width (experiments; reported in config)")
@@ -199,7 +200,7 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
         assert F > 0, "more ranks than 4-float column groups"
     ld = (F + args.ld_pad - 1) // args.ld_pad * args.ld_pad
     if partition == "features":
-        ld = (F + 15) // 16 * 16            # 64-byte rows: a narrow slab should not pay for padding it never reads
+        ld = (F + args.slab_pad - 1) // args.slab_pad * args.slab_pad
     comm, mu = (graphgen.COMMUNITY_SIZE, graphgen.COMMUNITY_MU) if graph.startswith("community") else (0, 1.0)
     events = []
     t_setup = time.time()

@@ -60,6 +60,9 @@ def test_golden_graphs(name):
 SHAPES = [  # n_rows, n_cols, avg_deg, F, hubs
     (300, 300, 6, 1, [(0, 100)]),
     (257, 400, 3, 3, []),
+    (500, 500, 12, 16, [(4, 3000)]),          # 4 float4 per row: 4-lane groups (feature-partition slabs)
+    (500, 600, 12, 24, [(4, 3000)]),          # 6 float4: 8-lane groups, two lanes idle
+    (800, 800, 10, 32, [(7, 2600)]),          # 8 float4: 8-lane groups
     (1000, 1000, 14, 47, [(17, 5000)]),
     (777, 900, 9, 100, [(5, 2500), (6, 9000)]),
     (1500, 1500, 7, 128, [(1, 20000)]),
