@@ -374,6 +374,32 @@ def build_feature_partitioned_graph(adj: SparseTensor, x_slab_fn: Callable, F: i
     return FeaturePartitionedGraph(adj, x, y, tmp, (c0, c1), F, adj.nnz(), n)
 
 
+def columns_to_rows(y_slab: torch.Tensor, F: int, group=None) -> torch.Tensor:
+    """Turn the column-sharded result of the feature partition ([N, w_g] on rank g) into a row-sharded one
+    ([N_g, F] on rank g, rows in ``graphgen.block_offsets(N, world)`` blocks) with ONE all-to-all: what a consumer
+    that needs whole rows (SGConv's ``lin``, a classifier) wants -- once per K-hop call, not once per hop."""
+    from .graphgen import block_offsets
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = y_slab.shape[0]
+    slabs = feature_slabs(F, world)
+    offs = block_offsets(n, world)
+    w = slabs[rank][1] - slabs[rank][0]
+    assert y_slab.shape[1] == w
+    n_mine = offs[rank + 1] - offs[rank]
+    send = y_slab.contiguous().reshape(-1)                        # row blocks are contiguous in a row-major slab
+    recv = torch.empty(n_mine * F, dtype=y_slab.dtype, device=y_slab.device)
+    in_splits = [(offs[r + 1] - offs[r]) * w for r in range(world)]
+    out_splits = [n_mine * (slabs[g][1] - slabs[g][0]) for g in range(world)]
+    _all_to_all(recv, send, out_splits, in_splits, group=group)
+    out = torch.empty((n_mine, F), dtype=y_slab.dtype, device=y_slab.device)
+    pos = 0
+    for g in range(world):
+        c0, c1 = slabs[g]
+        out[:, c0:c1] = recv[pos: pos + n_mine * (c1 - c0)].view(n_mine, c1 - c0)
+        pos += n_mine * (c1 - c0)
+    return out
+
+
 def sharded_edge_construction(pge_edge, Z: torch.Tensor, threshold: float, variant: str = "transductive", group=None):
     """``PGE_Edge.edge_construction`` over several GPUs (scorer row): the n x n pair grid is cut
     into row blocks, rank g scores rows [g*per, (g+1)*per) -- the n^2 x H x H GEMM, the only expensive part --

@@ -160,3 +160,30 @@ def test_global_graph_partition_khop(world, K, comm, mu, tmp_path):
     else:
         assert halo_frac < 0.3 and not any(p["dense"] for p in parts)
     assert all(p["desc"]["halo_edge_fraction"] == round(p["halo_nnz"] / p["nnz_local"], 4) for p in parts)
+
+
+def _c2r_worker(rank, world, port, n, F, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disco_amd.dist import columns_to_rows, feature_slabs
+        Y = torch.arange(n * F, dtype=torch.float32).view(n, F)
+        c0, c1 = feature_slabs(F, world)[rank]
+        buf = torch.zeros(n, c1 - c0 + 3)                         # a strided slab, as the propagation leaves it
+        buf[:, :c1 - c0] = Y[:, c0:c1]
+        rows = columns_to_rows(buf[:, :c1 - c0], F)
+        torch.save(rows, os.path.join(result_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,F", [(3, 50, 13), (2, 7, 602)])
+def test_columns_to_rows_redistribution(world, n, F, tmp_path):
+    """Feature partition -> row shards in one all-to-all (unequal slabs and row blocks)."""
+    from disco_amd.graphgen import block_offsets
+    mp.spawn(_c2r_worker, args=(world, _free_port(), n, F, str(tmp_path)), nprocs=world, join=True)
+    Y = torch.arange(n * F, dtype=torch.float32).view(n, F)
+    offs = block_offsets(n, world)
+    for r in range(world):
+        assert torch.equal(torch.load(tmp_path / f"r{r}.pt", weights_only=True), Y[offs[r]:offs[r + 1]])
