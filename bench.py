@@ -5,11 +5,13 @@ One "step" = one K=2 propagation  Y = A^2 X  over the whole graph (one pass of t
 synthetic input).
 
 N=1   the Reddit-shaped configuration (BASELINE.json configs[1]: 233k nodes, 114.6 M edges, F=602).
-N>1   ONE global graph, 1-D row-partitioned (disco_amd/dist.py): every rank generates exactly the entries of
-      its own rows of the global graph (drawn over the GLOBAL id range), halo feature rows are exchanged per hop
-      by RCCL (all-gather of the X shards or all-to-all of the needed rows, chosen from the halo that RESULTS)
-      and overlapped with the interior-block SpMM.  Headline = weak scaling: a graph of N x 233k nodes and
-      N x 114.6 M edges with the same mean degree (every rank owns a Reddit-sized row block).
+N>1   Headline = weak scaling: ONE global graph of N x 233k nodes and N x 114.6 M edges with the same mean degree,
+      run under two partitions (disco_amd/dist.py), the faster one reported as the headline, the other as an extra:
+      features  every rank holds the whole graph and F/N feature columns; A^K X is independent per column, so there is
+                NO exchange (the default whenever the graph fits one GPU's 288 GB);
+      rows      1-D row partition: every rank generates exactly the entries of its own rows (drawn over the GLOBAL id
+                range), halo feature rows are exchanged per hop by RCCL (all-gather of the X shards or all-to-all of
+                the needed rows, chosen from the halo that RESULTS) and overlapped with the interior-block SpMM.
       With WORLD_SIZE unset, `--gpus N` starts the N ranks itself (before any GPU call).
 
 Besides the headline the line carries `extra_workloads`: ogbn-products-shaped strong scaling (configs[2]: the
@@ -309,7 +311,7 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
         value /= gworld                   # one rank's share of the emulated job
     cfg.update({"nnz_per_rank": nnz, "rows_per_rank": n_local, "nnz_global": nnz_global, "setup_s": round(t_setup, 1)})
     res = {
-        "value": value, "ms_per_step": elapsed / steps * 1e3, "scaling": scaling, "n_gpus": world,
+        "value": value, "ms_per_step": elapsed / steps * 1e3, "scaling": scaling, "n_gpus": world, "partition": partition,
         "workload": f"{spec.name}{' (1/8-size square stand-in)' if name == 'papers100M-shard' else ''} K={K} GCN-normalised "
                     f"propagation, N={n_global}, nnz={nnz_global} (incl. self-loops), F={Fg}",
         "config": cfg,
@@ -436,44 +438,52 @@ def main():
         dist.init_process_group(ctx.backend, **({"device_id": ctx.dev} if ctx.backend == "nccl" else {}))
     t_start = time.time()
 
+    def headline(h):
+        return {"value": h["value"], "ms_per_step": h["ms_per_step"], "scaling": h["scaling"],
+                "config": dict(h["config"], workload=h["workload"]), "roofline": h["roofline"]}
+
+    # N > 1, --partition auto: the feature partition first (no collective on its data path: nothing in it can hang) ...
     head = run_spmm(ctx, args.workload, args.graph, args.steps, args.warmup, want_cpu=not args.no_cpu_baseline)
-    out = {
-        "metric": "K-hop SpMM edges*feat/s", "value": head["value"], "unit": "edges*feat/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
-        "scaling": head["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": dict(head["config"], workload=head["workload"]), "roofline": head["roofline"],
-    }
+    out = {"metric": "K-hop SpMM edges*feat/s", "value": None, "unit": "edges*feat/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+           "scaling": None, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": None, "roofline": None}
+    out.update(headline(head))
     if "cpu_baseline" in head:
         out["cpu_baseline"] = head["cpu_baseline"]
 
     extras = []
-    if args.extras != "none" and args.workload == "reddit" and args.graph == "config":
+    run_extras = args.extras != "none" and args.workload == "reddit" and args.graph == "config"
+    import threading
+
+    def give_up():
+        # ONE JSON line is printed.  Nothing after the first measurement may lose it: if the rest overruns its budget by
+        # two minutes (a hung collective, a rank that died), rank 0 prints the line with what it has and every rank leaves.
+        if rank0(ctx):
+            out["extra_workloads"] = extras + [{"aborted": "the remaining workloads overran their time budget"}]
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(max(1.0, args.extras_budget_s + 120.0 - (time.time() - t_start)) + (0 if rank0(ctx) else 5), give_up)
+    watchdog.daemon = True
+    if world > 1 or run_extras:
+        watchdog.start()
+    if run_extras:
         # (workload, generator, partition); partition None = --partition (auto: feature columns when the graph fits)
         plan = [("products", "config", None), ("products", "community", None)]
         if world > 1:
             plan = [("reddit", "community", None)] + plan
             if world == 8 or args.extras == "all":
                 plan += [("papers100M", "config", None), ("papers100M", "community", None)]
-            # the 1-D row partition with halo exchange (north_star's design for graphs that exceed one GPU), for comparison
-            plan += [("products", "config", "rows"), ("products", "community", "rows"), ("reddit", "config", "rows")]
+            # The 1-D row partition with halo exchange over RCCL (north_star's design for graphs that exceed one GPU) comes
+            # last: first the headline workload again -- the faster of its two partitions becomes the headline, the other
+            # one stays in this list -- then the strong-scaling graphs.
+            if args.partition == "auto" and head.get("partition") == "features":
+                plan += [("headline", args.graph, "rows")]
+            plan += [("products", "config", "rows"), ("products", "community", "rows")]
             if world == 8 or args.extras == "all":
                 plan += [("papers100M", "community", "rows")]
         else:
             plan += [("scorer", "", None)]
-        # ONE JSON line is printed, at the end.  The extra workloads must not be able to lose the headline: if they
-        # overrun their budget by two minutes (a hung collective, a rank that died), rank 0 prints the line with what
-        # it has and every rank leaves.
-        import threading
-
-        def give_up():
-            if rank0(ctx):
-                out["extra_workloads"] = extras + [{"aborted": "extra workloads overran their time budget"}]
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-
-        watchdog = threading.Timer(max(1.0, args.extras_budget_s + 120.0 - (time.time() - t_start)) + (0 if rank0(ctx) else 5), give_up)
-        watchdog.daemon = True
-        watchdog.start()
         for name, graph, part in plan:
             go = 1 if time.time() - t_start < args.extras_budget_s else 0
             if world > 1:       # rank 0 decides for everybody
@@ -487,6 +497,13 @@ def main():
             try:
                 if name == "scorer":
                     r = run_scorer(ctx, max(1, min(args.steps, 3)), 1)
+                elif name == "headline":
+                    r = run_spmm(ctx, args.workload, graph, args.steps, args.warmup, partition=part)
+                    r["unit"] = "edges*feat/s"
+                    if r["value"] > head["value"]:        # the same on every rank: times are maxima over the ranks
+                        head, r = r, head
+                        out.update(headline(head))
+                    r["note"] = "the headline workload under the other partition"
                 else:
                     r = run_spmm(ctx, name, graph, args.steps, args.warmup, partition=part)
                     r["unit"] = "edges*feat/s"
@@ -497,7 +514,8 @@ def main():
                     break
                 continue
             extras.append(r)
-        watchdog.cancel()
+    watchdog.cancel()
+    if extras:
         out["extra_workloads"] = extras
     if rank0(ctx):
         print(json.dumps(out), flush=True)

@@ -113,6 +113,7 @@ class RowPartition:
             owner = torch.bucketize(hcol, bounds[1:], right=True)
             self.adj_halo = SparseTensor(row=hrow, col=owner * self.per + (hcol - bounds[owner]), value=hval,
                                          sparse_sizes=(self.n_local, world * self.per), is_sorted=True)
+            self.adj_halo._active_col_frac = (world - 1) / world      # the rank's own shard of the table is never gathered
             self.send_idx = torch.empty(0, dtype=torch.int64, device=dev)
             self.send_splits = self.recv_splits = [0] * world
             return

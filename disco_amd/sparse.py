@@ -437,7 +437,10 @@ class SparseTensor:
         if n == 0 or m == 0 or self.nnz() >= 2 ** 32 - 1:
             return False
         windows = (m + sweep_window_rows(feat) - 1) // sweep_window_rows(feat)
-        if not (windows >= 2 and self.nnz() / n >= 8.0 * windows):
+        # windows no row has entries in cost next to nothing (a visit without entries leaves the row alone): the halo block
+        # over an all-gathered table never touches the rank's own shard (dist.RowPartition sets the fraction)
+        busy = max(1.0, windows * float(self.__dict__.get("_active_col_frac", 1.0)))
+        if not (windows >= 2 and self.nnz() / n >= 8.0 * busy):
             return False
         # ... and only when a row's entries are spread over the windows.  On a graph whose ids already follow its
         # communities a row has most of its entries in ONE window: a launch per window then leaves most lane groups
