@@ -527,6 +527,17 @@ __global__ __launch_bounds__(64) void k_sym_fill(const float* __restrict__ S, in
 
 using namespace disco;
 
+static int scorer_cus() {      // compute units of the current device (256 on MI355X), asked once
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus = v;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+
 extern "C" size_t disco_pairscore_workspace_bytes(int64_t n, int64_t H) {
   if (n < 0 || H <= 0) return 0;
   return (size_t)scorer_layout(n, H).total;
@@ -561,7 +572,8 @@ template <int H>
 static int launch_pairs(const char* w, const ScorerWs& L, int64_t i0, int64_t i1, int64_t j0, int64_t j1, float* out, int64_t ldo,
                         int apply_sigmoid, hipStream_t s) {
   const int64_t tiles = (i1 - i0) * ((j1 - j0 + 63) / 64);
-  int64_t blocks = tiles < 256 * 4 ? tiles : 256 * 4;
+  const int64_t resident = (int64_t)scorer_cus() * 4;       // persistent workgroups: four per CU share the tile loop
+  int64_t blocks = tiles < resident ? tiles : resident;
   if (blocks < 1) return DISCO_OK;
   const size_t lds_bytes = (size_t)(2 * 64 * (H + 4) + 2 * 8 * 64) * sizeof(float);
   static bool attr_set = false;      // per instantiation: raised once, not on every launch
@@ -624,7 +636,8 @@ static int launch_edges(const char* w, const ScorerWs& L, int64_t n, float thr, 
                         int64_t cap, unsigned long long* counter, hipStream_t s) {
   const int64_t B = (n + 63) / 64;
   const int64_t n_pairs = B * (B + 1) / 2 * 64;
-  int64_t blocks = n_pairs < 256 * 4 ? n_pairs : 256 * 4;
+  const int64_t resident = (int64_t)scorer_cus() * 4;
+  int64_t blocks = n_pairs < resident ? n_pairs : resident;
   if (blocks < 1) return DISCO_OK;
   const size_t lds_bytes = (size_t)(2 * 64 * (H + 4) + 2 * 8 * 64) * sizeof(float);
   static bool attr_set = false;      // per instantiation: the dynamic LDS limit is raised once, not on every launch
