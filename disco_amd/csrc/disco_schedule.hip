@@ -247,7 +247,7 @@ static int schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz, in
   info->off_perm = L.off_perm; info->off_piece_row = L.off_piece_row; info->off_piece_begin = L.off_piece_begin;
   info->off_piece_end = L.off_piece_end; info->off_piece_slot = L.off_piece_slot;
   info->off_multi_row = L.off_multi_row; info->off_multi_first = L.off_multi_first; info->ws_bytes = L.total;
-  info->xcd_run = grouped ? 128 : 0;     // measured on the products-shaped community graph (profiles/r2/locality_order_sweep.log)
+  info->xcd_run = grouped ? 1024 : 0;    // rows; callers that know their group sizes set it to the typical size (sparse.py)
   if (n_rows == 0) return DISCO_OK;
 
   char* ws = static_cast<char*>(sched_ws);

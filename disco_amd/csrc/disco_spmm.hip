@@ -711,9 +711,9 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
   if (count > 0 && !swept) {
     int64_t blocks = (count + 4 * RPW - 1) / (4 * RPW);
     int64_t xcd_chunk = 0;
-    const int64_t xcd_run = tuning().xcd_map >= 0 ? tuning().xcd_map : (a.info ? a.info->xcd_run : 0);
-    if (xcd_run > 0 && perm && blocks >= 64) {    // 1: one contiguous eighth per XCD; S > 1: runs of S blocks
-      xcd_chunk = xcd_run == 1 ? (blocks + 7) / 8 : std::min<int64_t>(xcd_run, (blocks + 63) / 64);
+    const int64_t xcd_run = tuning().xcd_map >= 0 ? tuning().xcd_map : (a.info ? a.info->xcd_run : 0);   // in ROWS
+    if (xcd_run > 0 && perm && blocks >= 64) {    // 1: one contiguous eighth per XCD; S > 1: runs of S rows
+      xcd_chunk = xcd_run == 1 ? (blocks + 7) / 8 : std::min<int64_t>(std::max<int64_t>(1, xcd_run / (4 * RPW)), (blocks + 63) / 64);
       blocks = (blocks + 8 * xcd_chunk - 1) / (8 * xcd_chunk) * (8 * xcd_chunk);
     }
     if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;

@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import math
+
 import torch
 
 from . import _lib
@@ -245,6 +247,7 @@ class SparseTensor:
         out._sweep, out._sweep_force, out._window_bytes = self._sweep, self._sweep_force, self._window_bytes
         out._shared = self._shared
         out._row_groups = self._row_groups
+        out._xcd_run = getattr(self, "_xcd_run", 0)
         return out
 
     def fill_value(self, fill: float, dtype=torch.float32) -> "SparseTensor":
@@ -346,6 +349,8 @@ class SparseTensor:
                                                                     _lib.ptr(self._row_groups), _lib.ptr(ws), ws.numel(), info,
                                                                     _lib.current_stream(self.device)),
                                    "disco_schedule_build_grouped")
+                        if getattr(self, "_xcd_run", 0):
+                            info.xcd_run = self._xcd_run
                     else:
                         nbytes = lib.disco_schedule_workspace_bytes(n, nnz, hub_threshold, hub_piece)
                         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
@@ -420,6 +425,13 @@ class SparseTensor:
             assert groups.numel() == self._sizes[0] and groups.device == self.device
             groups = groups.to(torch.int32).contiguous()
         self._row_groups = groups
+        # run length of the XCD-aware workgroup order: the size of the group a typical row lives in (sum size^2 / sum size),
+        # as a power of two in [256, 8192] rows
+        self._xcd_run = 0
+        if groups is not None and groups.numel():
+            sizes = torch.bincount(groups.long()).double()
+            typical = float((sizes * sizes).sum() / sizes.sum())
+            self._xcd_run = int(min(8192, max(256, 2 ** round(math.log2(max(typical, 1.0))))))
         self._sched, self._sweep = None, None
         old, self._shared = self._shared, _StructCache()          # schedules are per row order; the transpose is not
         self._shared.t_struct, self._shared.t_perm = old.t_struct, old.t_perm
