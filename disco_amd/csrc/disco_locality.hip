@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void k_lpa_step(const int64_t* __restrict__ ro
   uint32_t* k = keys[wave];
   uint32_t* c = cnts[wave];
   for (int s = lane; s < kLpaSlots; s += 64) { k[s] = kLpaEmpty; c[s] = 0u; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the table is wave-private: order its phases within the wave
   bool overflow = false;
   auto tally = [&](uint32_t label) {
     uint32_t slot = (label * kLpaHashMul) >> 22;                // 10 bits
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void k_lpa_step(const int64_t* __restrict__ ro
     if (u != v && u < n) tally(in[u]);
   }
   (void)overflow;   // a row with more distinct neighbour labels than slots decides on the votes that fitted
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   uint32_t chosen = own;
   for (int attempt = 0; attempt < (CAPPED ? 3 : 1); ++attempt) {
     // most frequent label, ties to the smaller hash (a bijection of the label): max of (count, ~hash)
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(256) void k_lpa_step(const int64_t* __restrict__ ro
     if (ok) { chosen = want; break; }
     for (int s = lane; s < kLpaSlots; s += 64)                   // strike the full group and choose again
       if (k[s] == want) c[s] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   if (lane == 0) out[v] = chosen;
 }
