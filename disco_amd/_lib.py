@@ -54,6 +54,8 @@ _SIGNATURES = {
     "disco_csr_rowsum_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "disco_gcn_norm_csr_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "disco_degree_count_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "disco_degree_count_sorted_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "disco_degree_count_sorted_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "disco_degree_ordered_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "disco_inv_sqrt_f32": (c_int, [c_void_p, c_int64, c_void_p]),
     "disco_gcn_norm_coo_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -112,7 +112,13 @@ def gcn_norm(edge_index: Union[torch.Tensor, SparseTensor], edge_weight: Optiona
         s = _lib.current_stream(dev)
         deg = torch.empty(num_nodes, dtype=torch.float32, device=dev)
         if edge_weight is None:
-            _lib.check(lib.disco_degree_count_f32(_lib.ptr(idx), E, num_nodes, _lib.ptr(deg), s), "disco_degree_count_f32")
+            if E >= (1 << 20):      # many edges: sort + run lengths beats one global atomic per edge (same integers)
+                ws = torch.empty(max(int(lib.disco_degree_count_sorted_workspace_bytes(E, num_nodes)), 256), dtype=torch.uint8, device=dev)
+                _lib.check(lib.disco_degree_count_sorted_f32(_lib.ptr(idx), E, num_nodes, _lib.ptr(deg), _lib.ptr(ws), ws.numel(), s),
+                           "disco_degree_count_sorted_f32")
+                del ws
+            else:
+                _lib.check(lib.disco_degree_count_f32(_lib.ptr(idx), E, num_nodes, _lib.ptr(deg), s), "disco_degree_count_f32")
             w = None
         else:
             w = edge_weight.to(torch.float32).contiguous()

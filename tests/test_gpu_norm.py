@@ -47,6 +47,36 @@ def test_gcn_norm_random_bit_exact(weighted, flow):
     assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32))
 
 
+def test_sorted_degree_count_equals_atomic_count():
+    """disco_degree_count_sorted_f32 (radix sort + run lengths, what gcn_norm uses from 2^20 edges on) against
+    disco_degree_count_f32 (atomics) and numpy: hubs, isolated nodes, ids outside [0, N) ignored, empty list."""
+    from disco_amd import _lib, utils
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    n, E = 70_001, 1_500_000
+    idx = rng.integers(0, n, E)
+    idx[rng.random(E) < 0.2] = 17                         # a hub
+    idx[idx == 40_000] = 3                                # an isolated node
+    idx[:5] = [-1, n, n + 7, -9, 2 ** 40]                 # out of range: ignored
+    d = torch.from_numpy(idx).to(DEV)
+    s = _lib.current_stream(torch.device(DEV))
+    ref = np.bincount(idx[(idx >= 0) & (idx < n)], minlength=n).astype(np.float32)
+    a = torch.full((n,), -1.0, device=DEV)
+    b = torch.full((n,), -1.0, device=DEV)
+    ws = torch.empty(int(lib.disco_degree_count_sorted_workspace_bytes(E, n)), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.disco_degree_count_f32(_lib.ptr(d), E, n, _lib.ptr(a), s), "atomic")
+    _lib.check(lib.disco_degree_count_sorted_f32(_lib.ptr(d), E, n, _lib.ptr(b), _lib.ptr(ws), ws.numel(), s), "sorted")
+    assert np.array_equal(a.cpu().numpy(), ref) and np.array_equal(b.cpu().numpy(), ref) and ref[40_000] == 0
+    _lib.check(lib.disco_degree_count_sorted_f32(None, 0, n, _lib.ptr(b), None, 0, s), "empty")
+    assert float(b.abs().sum()) == 0.0
+    assert lib.disco_degree_count_sorted_f32(_lib.ptr(d), E, n, _lib.ptr(b), _lib.ptr(ws), 16, s) == -3      # DISCO_EWORKSPACE
+    # through utils.gcn_norm (>= 2^20 edges: the sorted path), bit exact against the oracle
+    ei = np.stack([rng.integers(0, n, E), idx.clip(0, n - 1)])
+    _, refw = orc.gcn_norm_coo(ei, None, n, add_self_loops=False)
+    _, got = utils.gcn_norm(torch.from_numpy(ei).to(DEV), None, n, add_self_loops=False)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), refw.view(np.uint32))
+
+
 @pytest.mark.parametrize("name", GRAPHS)
 def test_normalize_adj_tensor_golden(name):
     from disco_amd import utils
