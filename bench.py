@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--exchange", default="auto", choices=["auto", "need", "dense"], help="N > 1: halo exchange")
     ap.add_argument("--extras", default="auto", choices=["auto", "none", "all"],
                     help="extra workloads in the line (auto: products strong scaling, community variants, papers100M at N=8)")
-    ap.add_argument("--extras-budget-s", type=float, default=420.0, help="skip the remaining extras after this many seconds")
+    ap.add_argument("--extras-budget-s", type=float, default=300.0, help="skip the remaining extras after this many seconds")
     ap.add_argument("--tune", default="", help="comma-separated key=value pairs for disco_set_tuning (experiments)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workloads (debug only; reported in config)")
     return ap.parse_args()
