@@ -459,8 +459,7 @@ def main():
         # ONE JSON line is printed.  Nothing after the first measurement may lose it: if the rest overruns its budget by
         # two minutes (a hung collective, a rank that died), rank 0 prints the line with what it has and every rank leaves.
         if rank0(ctx):
-            out["extra_workloads"] = extras + [{"aborted": "the remaining workloads overran their time budget"}]
-            print(json.dumps(out), flush=True)
+            emit(out, extras + [{"aborted": "the remaining workloads overran their time budget"}], world)
         os._exit(0)
 
     watchdog = threading.Timer(max(1.0, args.extras_budget_s + 120.0 - (time.time() - t_start)) + (0 if rank0(ctx) else 5), give_up)
@@ -515,16 +514,61 @@ def main():
                 continue
             extras.append(r)
     watchdog.cancel()
-    if extras:
-        out["extra_workloads"] = extras
     if rank0(ctx):
-        print(json.dumps(out), flush=True)
+        emit(out, extras, world)
     if world > 1:
         dist.destroy_process_group()
 
 
 def rank0(ctx: Ctx) -> bool:
     return ctx.rank == 0
+
+
+def compact_extra(e: dict) -> dict:
+    """One extra workload in a few dozen bytes: whoever captures stdout may keep only its tail, so the ONE line
+    stays short; everything else goes to stderr and gpurun_out/bench_detail_n<N>.json."""
+    if "failed" in e or "skipped" in e or "aborted" in e:
+        return {k: (str(v)[:120]) for k, v in e.items() if k in ("workload", "failed", "skipped", "aborted")}
+    c = e.get("config", {})
+    par = c.get("parallelism", "")
+    out = {"workload": e.get("workload", "").split(" K=")[0].split(",")[0][:44], "ms_per_step": round(e["ms_per_step"], 3),
+           "value": float(f"{e['value']:.4g}"), "frac": e.get("roofline", {}).get("frac")}
+    if e.get("unit", "edges*feat/s") != "edges*feat/s":
+        out["unit"] = e["unit"]
+    if "graph" in c:
+        out["graph"] = c["graph"].split(",")[0][:28]
+    if par and par != "single":
+        out["partition"] = "features" if par.startswith("feature") else "rows"
+    if c.get("row_order") == "locality":
+        out["row_order"] = "locality"
+    if "note" in e:
+        out["note"] = e["note"]
+    return out
+
+
+def emit(out: dict, extras: list, n_gpus: int) -> None:
+    """Print THE line (compact) on stdout; the full record goes to stderr and, when possible, to a file."""
+    full = dict(out)
+    if extras:
+        full["extra_workloads"] = extras
+    line = dict(out)
+    if extras:
+        line["extra_workloads"] = [compact_extra(e) for e in extras]
+    cb = line.get("cpu_baseline")
+    if cb and "torch_forms" in cb:
+        cb = dict(cb)
+        cb["sample"] = cb["sample"].split(" at F=")[0] + ", oracle/spmm_ref.c (OpenMP)"
+        cb["torch_forms"] = [{"form": t["form"].split(" (")[0], "value": float(f"{t['value']:.4g}"), "cores": t["cores"]} for t in cb["torch_forms"]]
+        line["cpu_baseline"] = cb
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", f"bench_detail_n{n_gpus}.json"), "w") as fh:
+            json.dump(full, fh)
+        line["detail"] = f"gpurun_out/bench_detail_n{n_gpus}.json (also on stderr)"
+    except OSError:
+        line["detail"] = "stderr"
+    print("BENCH_DETAIL " + json.dumps(full), file=sys.stderr, flush=True)
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

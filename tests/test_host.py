@@ -206,3 +206,26 @@ def test_bench_byte_models_and_graph_sizes():
     assert (n, nnz, scaling) == (2_449_029, 61_859_140, "strong")
     s, n, nnz, scaling = bench.graph_params("papers100M", A, 1)
     assert (n, nnz) == (111_059_956, 1_615_685_872)
+
+
+def test_bench_line_stays_short(capsys, tmp_path, monkeypatch):
+    """Whoever captures bench.py's stdout may keep only its tail: the ONE line is compact (extras in a few dozen bytes
+    each), the full record goes to stderr and a file."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r2", "bench_default_n1.json")).read().strip().splitlines()[-1])
+    extras = full.pop("extra_workloads")
+    extras = extras * 4 + [{"workload": "x", "failed": "RuntimeError: " + "y" * 500}, {"workload": "z", "skipped": "time budget"}]
+    bench.emit(full, extras, 8)
+    cap = capsys.readouterr()
+    lines = [l for l in cap.out.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4200, len(lines[0])
+    line = json.loads(lines[0])
+    assert line["value"] == full["value"] and line["roofline"] == full["roofline"] and len(line["extra_workloads"]) == len(extras)
+    assert all(len(json.dumps(e)) < 260 for e in line["extra_workloads"])
+    assert cap.err.startswith("BENCH_DETAIL ") and json.loads(cap.err[len("BENCH_DETAIL "):])["extra_workloads"][0] == extras[0]
+    assert json.load(open(tmp_path / "gpurun_out" / "bench_detail_n8.json"))["value"] == full["value"]
