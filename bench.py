@@ -20,8 +20,9 @@ variants of the generators (graphgen.py) -- see DESIGN.md section 4.
 
 Prints the JSON line on rank 0 (contract in the task statement): value = edges*feat/s of the whole job, plus
 `roofline` (dominant kernel, live HIP-event timing) and `cpu_baseline` (N=1 only: the oracle's OpenMP C port and
-BASELINE.md's two torch forms, on a bounded sample).  Exactly one line is printed; a watchdog prints it with what
-has been measured if the extra workloads overrun their budget, so that nothing inside an extra can lose the headline.
+BASELINE.md's two torch forms, on a bounded sample).  Exactly one line is printed, compact (the headline in full, extras
+in a few dozen bytes each; the complete record goes to stderr and gpurun_out/bench_detail_n<N>.json); a watchdog prints it
+with what has been measured if the extra workloads overrun their budget, so that nothing inside an extra can lose the headline.
 """
 from __future__ import annotations
 
