@@ -76,6 +76,8 @@ _SIGNATURES = {
     "disco_csr_insert_diagonal": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                           C.POINTER(c_int64), c_void_p, c_size_t, c_void_p]),
     "disco_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "disco_anchor_max_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                     c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "disco_pair_gather_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                       c_void_p, c_int64, c_void_p, c_void_p]),
 }

@@ -50,9 +50,87 @@ __global__ void k_gather_rows(const float* __restrict__ x, int64_t ldx, int wv, 
   *reinterpret_cast<V*>(out + i * ldo + (int64_t)k * VW) = *reinterpret_cast<const V*>(x + idx[i] * ldx + (int64_t)k * VW);
 }
 
+// Anchor neighbour features: out[dst(i), 0:width] = max_k T[map(anchor[i, k]), 0:width].
+// The reference forms feat_transform[index[c]][anchor, :L*d].max(dim=1).values
+// (/root/reference/LargeScaleCondensing.py:299; _induct.py:293; _Sampled.py:259-261): a row subset, an
+// [n_c, k, L*d] gather and a reduction.  Here one lane owns one 16/8/4-byte vector of one output row and keeps the
+// running maximum in registers: k row reads + one row write, no intermediate, HBM bound.  The maximum follows
+// torch.max(dim): the first NaN met wins (it propagates), otherwise `v` replaces `m` when !(v <= m).
+template <typename V>
+__global__ void k_anchor_max(const float* __restrict__ T, int64_t n, int64_t ldt, int wv, const int64_t* __restrict__ row_map,
+                             int64_t n_map, const int64_t* __restrict__ anchor, int64_t n_out, int k,
+                             const int64_t* __restrict__ out_rows, int64_t n_dst, float* __restrict__ out, int64_t ldo,
+                             int* __restrict__ err) {
+  constexpr int VW = sizeof(V) / 4;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out * wv) return;
+  const int64_t i = t / wv;
+  const int c = (int)(t - i * wv);
+  float m[VW];
+  bool ok = true, first = true;
+#pragma unroll
+  for (int e = 0; e < VW; ++e) m[e] = 0.0f;
+  for (int j = 0; j < k; ++j) {
+    int64_t a = anchor[i * k + j];
+    if (row_map) {
+      if (a < 0 || a >= n_map) { ok = false; continue; }
+      a = row_map[a];
+    }
+    if (a < 0 || a >= n) { ok = false; continue; }
+    const V v = *reinterpret_cast<const V*>(T + a * ldt + (int64_t)c * VW);
+    const float* vf = reinterpret_cast<const float*>(&v);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      if (first) m[e] = vf[e];
+      else if (m[e] == m[e] && !(vf[e] <= m[e])) m[e] = vf[e];
+    }
+    first = false;
+  }
+  int64_t d = out_rows ? out_rows[i] : i;
+  if (d < 0 || d >= n_dst) { ok = false; d = -1; }
+  if (!ok && err) *err = 1;     // plain vector store of a constant: every writer writes the same value
+  if (d >= 0) {
+    V o;
+    float* of = reinterpret_cast<float*>(&o);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) of[e] = m[e];
+    *reinterpret_cast<V*>(out + d * ldo + (int64_t)c * VW) = o;
+  }
+}
+
 }  // namespace disco
 
 using namespace disco;
+
+extern "C" int disco_anchor_max_f32(const float* T, int64_t n, int64_t ldt, int64_t width, const int64_t* row_map, int64_t n_map,
+                                    const int64_t* anchor, int64_t n_out, int64_t k, const int64_t* out_rows, int64_t n_dst,
+                                    float* out, int64_t ldo, int* err_flag, void* stream_) {
+  if (n < 0 || width < 0 || n_out < 0 || k < 1 || k > 1024 || ldt < width || ldo < width || n_map < 0 || n_dst < 0) return DISCO_EINVAL;
+  if (n_out == 0 || width == 0) return DISCO_OK;
+  if (!T || !anchor || !out || (n_map > 0 && !row_map)) return DISCO_EINVAL;
+  if (!out_rows && n_dst < n_out) return DISCO_EINVAL;
+  auto aligned = [&](int a) {
+    return width % a == 0 && ldt % a == 0 && ldo % a == 0 && (reinterpret_cast<uintptr_t>(T) % (4 * a)) == 0 &&
+           (reinterpret_cast<uintptr_t>(out) % (4 * a)) == 0;
+  };
+  const int vw = aligned(4) ? 4 : aligned(2) ? 2 : 1;
+  const int64_t wv = width / vw;
+  const int64_t blocks = (n_out * wv + 255) / 256;
+  if (blocks > 0x7fffffffLL || wv > 0x3fffffff) return DISCO_EUNSUPPORTED;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int64_t* rm = n_map > 0 ? row_map : nullptr;
+  if (vw == 4)
+    hipLaunchKernelGGL(k_anchor_max<float4>, dim3((unsigned)blocks), dim3(256), 0, stream, T, n, ldt, (int)wv, rm, n_map, anchor, n_out,
+                       (int)k, out_rows, n_dst, out, ldo, err_flag);
+  else if (vw == 2)
+    hipLaunchKernelGGL(k_anchor_max<float2>, dim3((unsigned)blocks), dim3(256), 0, stream, T, n, ldt, (int)wv, rm, n_map, anchor, n_out,
+                       (int)k, out_rows, n_dst, out, ldo, err_flag);
+  else
+    hipLaunchKernelGGL(k_anchor_max<float>, dim3((unsigned)blocks), dim3(256), 0, stream, T, n, ldt, (int)wv, rm, n_map, anchor, n_out,
+                       (int)k, out_rows, n_dst, out, ldo, err_flag);
+  DISCO_CHECK_LAUNCH();
+  return DISCO_OK;
+}
 
 extern "C" int disco_gather_rows_f32(const float* x, int64_t ldx, int64_t width, const int64_t* idx, int64_t n_idx, float* out,
                                      int64_t ldo, void* stream_) {

@@ -26,6 +26,31 @@ def edge_translation_features(adj_t: SparseTensor, feat: torch.Tensor) -> torch.
     return torch.cat([feat, ops.max_aggregate(adj_t, feat)], dim=1)
 
 
+def anchor_neighbor_features(feat_syn: torch.Tensor, feat_transform: torch.Tensor, anchors, index, index_syn,
+                             width: Optional[int] = None) -> torch.Tensor:
+    """``feat_syn_transform`` of ``edge_construction`` (/root/reference/LargeScaleCondensing.py:292-300,
+    _induct.py:284-295, _Sampled.py:252-262): per class c the synthetic nodes ``index_syn[c]`` take the element-wise
+    maximum, over their ``neighbor`` (3) nearest real train nodes ``index[c][anchors[c]]``, of the first ``width``
+    (= aggr_layer * d) columns of ``feat_transform``; the result is concatenated behind ``feat_syn``.
+
+    anchors / index / index_syn: dicts (or sequences) keyed by class, as the reference's ``knn_class[c].search``
+    result, ``index[c]`` and ``index_syn[c]``; classes missing from ``anchors`` keep zeros (``num_class_dict``).
+    The k-NN search itself (faiss, CPU) is outside the path.  One ``disco_anchor_max_f32`` call per class writes
+    straight into the output rows: no row-subset copy, no [n_c, 3, L*d] intermediate."""
+    width = feat_transform.shape[1] if width is None else int(width)
+    out = torch.zeros((feat_syn.shape[0], feat_syn.shape[1] + width), dtype=torch.float32, device=feat_syn.device)
+    out[:, : feat_syn.shape[1]] = feat_syn
+    neigh = out[:, feat_syn.shape[1]:]
+    keys = anchors.keys() if hasattr(anchors, "keys") else range(len(anchors))
+    for c in keys:
+        a = torch.as_tensor(anchors[c], device=feat_syn.device)
+        if a.numel() == 0:
+            continue
+        ops.anchor_max(feat_transform, a, width, index=torch.as_tensor(index[c]), out=neigh,
+                       out_rows=torch.as_tensor(index_syn[c]))
+    return out
+
+
 def negative_sampling(edge_index: torch.Tensor, num_nodes: int, num_neg_samples: int,
                       generator: Optional[torch.Generator] = None) -> torch.Tensor:
     """PyG ``negative_sampling(edge_index, num_nodes, num_neg_samples)`` [upstream, restated]

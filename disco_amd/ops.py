@@ -4,6 +4,7 @@ current HIP stream and call the C ABI (include/disco_hip.h).  No CPU fallback ex
 spmm       <- torch_sparse.matmul(adj_t, x, reduce)      sg_conv.py:92-93, gcn_conv.py:170-171
 khop       <- for k in range(K): x = propagate(adj_t, x)  sg_conv.py:74-77
 max_aggregate <- MessagePassing(aggr="max").propagate     LargeScaleCondensing.py:152-172
+anchor_max <- feat_transform[index[c]][anchor, :L*d].max(dim=1).values   LargeScaleCondensing.py:299
 (paths relative to /root/reference)
 """
 from __future__ import annotations
@@ -200,3 +201,54 @@ def pair_gather(z: torch.Tensor, edge_index: torch.Tensor, sel: Optional[torch.T
     if own_flag and int(err_flag.item()):
         raise IndexError("pair_gather: edge selection or node index out of range")
     return out
+
+
+def anchor_max(feat_transform: torch.Tensor, anchor: torch.Tensor, width: Optional[int] = None,
+               index: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+               out_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``feat_transform[index][anchor, :width].max(dim=1).values`` in one kernel -- the anchor neighbour features of
+    ``edge_construction`` (/root/reference/LargeScaleCondensing.py:293-300, _induct.py:284-294, _Sampled.py:252-262).
+
+    anchor   int64 [n_c, k]: per synthetic node the k nearest real nodes (k = 3 in the reference), as positions in
+             ``index`` when that is given (faiss searches the class's train rows), else as rows of feat_transform;
+    width    the column cut ``:(aggr_layer)*d`` (default: every column);
+    out / out_rows  write row i to ``out[out_rows[i]]`` (``feat_syn_neighbor[index_syn[c]] = ...``); without them a
+             fresh [n_c, width] tensor is returned."""
+    if not (feat_transform.is_cuda and anchor.is_cuda):
+        raise RuntimeError("disco_amd.anchor_max needs CUDA (HIP) tensors: there is no CPU fallback")
+    if anchor.dim() != 2:
+        raise ValueError("anchor must be [n_c, k]")
+    t = _as_operand(feat_transform)
+    n, full = t.shape
+    width = full if width is None else int(width)
+    if not 0 <= width <= full:
+        raise ValueError(f"width {width} outside [0, {full}]")
+    anchor = anchor.to(torch.int64).contiguous()
+    n_c, k = anchor.shape
+    if index is not None:
+        index = index.to(device=t.device, dtype=torch.int64).contiguous()
+    if out_rows is not None:
+        if out is None:
+            raise ValueError("out_rows needs out")
+        out_rows = out_rows.to(device=t.device, dtype=torch.int64).contiguous()
+        if out_rows.numel() != n_c:
+            raise ValueError("out_rows must name one destination row per anchor row")
+    if out is None:
+        out = _padded_empty(n_c, width, t.device)
+    if out.dim() != 2 or out.shape[1] < width or out.stride(1) != 1 or out.dtype != torch.float32 or out.device != t.device:
+        raise ValueError("out must be a float32 [rows, >= width] matrix on the same device")
+    if out_rows is None and out.shape[0] < n_c:
+        raise ValueError("out has fewer rows than anchor")
+    if n_c == 0 or width == 0:
+        return out if out_rows is not None else out[:n_c, :width]
+    if k < 1:
+        raise ValueError("anchor needs at least one column")
+    err = torch.zeros(1, dtype=torch.int32, device=t.device)
+    lib = _lib.load()
+    with torch.cuda.device(t.device):
+        _lib.check(lib.disco_anchor_max_f32(_lib.ptr(t), n, t.stride(0), width, _lib.ptr(index), 0 if index is None else index.numel(),
+                                            _lib.ptr(anchor), n_c, k, _lib.ptr(out_rows), out.shape[0], _lib.ptr(out), out.stride(0),
+                                            _lib.ptr(err), _lib.current_stream(t.device)), "disco_anchor_max_f32")
+    if int(err.item()):
+        raise IndexError("anchor_max: an anchor, index or destination row is out of range")
+    return out if out_rows is not None else out[:n_c, :width]

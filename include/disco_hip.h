@@ -334,6 +334,21 @@ int disco_pair_gather_f32(const float* Z, int64_t n, int64_t ldz, int64_t width,
 int disco_gather_rows_f32(const float* x, int64_t ldx, int64_t width, const int64_t* idx, int64_t n_idx, float* out,
                           int64_t ldo, void* stream);
 
+/* ---- Anchor neighbour features of edge_construction -----------------------------------
+ * out[dst(i), 0:width] = max over j < k of T[map(anchor[i*k + j]), 0:width],  i < n_out
+ *   map(a) = row_map ? row_map[a] : a      (row_map int64[n_map]: the class's train rows, `index[c]`; n_map = 0: none)
+ *   dst(i) = out_rows ? out_rows[i] : i    (out_rows int64[n_out]: the class's synthetic rows, `index_syn[c]`)
+ * Replaces `feat_syn_neighbor[index_syn[c]] = feat_transform[index[c]][anchor, :L*d].max(dim=1).values`
+ * (/root/reference/LargeScaleCondensing.py:299; LargeScaleCondensing_induct.py:293;
+ * LargeScaleCondensing_Sampled.py:259-261) without the row-subset copy and the [n_c, k, L*d] intermediate.
+ * T is [n, ldt] float32, `width` <= ldt the column cut `:L*d`, anchor int64 [n_out, k] row-major (k = 3 in the
+ * reference), out [n_dst, ldo].  The maximum follows torch.max(dim): a NaN propagates.  An index outside its range
+ * is skipped (an out-of-range destination row is not written) and sets *err_flag (optional device int, cleared by
+ * the caller) to 1.  Rows of out that no dst(i) names are left untouched.  Nothing synchronises. */
+int disco_anchor_max_f32(const float* T, int64_t n, int64_t ldt, int64_t width, const int64_t* row_map, int64_t n_map,
+                         const int64_t* anchor, int64_t n_out, int64_t k, const int64_t* out_rows, int64_t n_dst,
+                         float* out, int64_t ldo, int* err_flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

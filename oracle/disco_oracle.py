@@ -312,10 +312,18 @@ def edge_translation_features(rowptr, col, x):
     return np.concatenate([x, max_aggregate(rowptr, col, x)], axis=1)
 
 
-def anchor_max(feat_transform_rows, anchor):
-    """/root/reference/LargeScaleCondensing.py:299: ``T[anchor].max(dim=1)`` --
-    per synthetic node the element-wise max over its anchors' rows."""
-    return np.asarray(feat_transform_rows)[np.asarray(anchor)].max(axis=1)
+def anchor_max(feat_transform_rows, anchor, width=None, index=None):
+    """/root/reference/LargeScaleCondensing.py:299 (``_induct.py:293``, ``_Sampled.py:259-261``):
+    ``feat_transform[index[c]][anchor, :L*d].max(dim=1).values`` -- per synthetic node the
+    element-wise max over its anchors' rows; ``index`` selects the class's train rows first,
+    ``width`` is the column cut ``:L*d``.  NaN propagates (torch.max / np.max alike)."""
+    t = np.asarray(feat_transform_rows)
+    if index is not None:
+        t = t[np.asarray(index)]
+    g = t[np.asarray(anchor)]
+    if width is not None:
+        g = g[:, :, :width]
+    return g.max(axis=1)
 
 
 # --------------------------------------------------------------------------

@@ -245,3 +245,17 @@ def test_gcn_norm_sparse_branch_oracle_closed_form():
     assert np.allclose(dense, want, rtol=3e-7)
     r2, c2, v2 = orc.gcn_norm_sparse(ei[0], ei[1], None, 5, add_self_loops=False)
     assert len(v2) == 7 and np.isclose(v2[(r2 == 1) & (c2 == 1)][0], 1 / 3.0, rtol=3e-7)
+
+
+def test_anchor_max_restatement_matches_torch_indexing():
+    """A8 (/root/reference/LargeScaleCondensing.py:299): the oracle's numpy form equals the reference's torch
+    expression ``feat_transform[index[c]][anchor, :L*d].max(dim=1).values`` evaluated with stock torch."""
+    import torch
+    rng = np.random.default_rng(3)
+    T = rng.standard_normal((200, 24)).astype(np.float32)
+    index_c = rng.permutation(200)[:70]
+    anchor = rng.integers(0, 70, (31, 3))
+    anchor[0] = anchor[0, 0]
+    want = torch.from_numpy(T)[torch.from_numpy(index_c)][torch.from_numpy(anchor), :16].max(dim=1).values.numpy()
+    assert np.array_equal(orc.anchor_max(T, anchor, 16, index=index_c), want)
+    assert np.array_equal(orc.anchor_max(T[index_c], anchor), torch.from_numpy(T[index_c])[torch.from_numpy(anchor)].max(dim=1).values.numpy())
