@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+BASELINE_CONFIG = {"products": "configs[2]", "papers100M": "configs[4]"}   # BASELINE.json entries that name the row partition
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 
 
@@ -289,6 +290,7 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
         ev3 = []
 
         def step(record: bool):
+            g.part.time_waits = record        # events around every wait for the exchange: the part compute did not cover
             g.khop(K, ev3 if record else None)
             if record:
                 events.extend((a, b) for a, b, _ in ev3)
@@ -305,6 +307,10 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
     elapsed = ctx.timed(step, warmup, steps)
     durs_ms = [a.elapsed_time(b) for a, b in events]
     hop_ms = sum(durs_ms) / max(len(durs_ms), 1)
+    if partition == "rows":
+        waits = g.part.exposed_wait_ms()
+        cfg["halo"]["exposed_exchange_ms_per_hop"] = round(sum(waits) / max(len(durs_ms), 1), 4)
+        cfg["halo"]["exchange_GBs_if_fully_exposed"] = round(cfg["halo"]["recv_bytes_per_hop"] / max(sum(waits) / max(len(durs_ms), 1), 1e-6) / 1e6, 1)
     algo = b_min_bytes(nnz, n_local, F)                      # this rank's share per hop
     achieved = algo / (hop_ms * 1e-3) / 1e9 if durs_ms else 0.0
     value = float(K) * nnz_global * Fg * steps / elapsed
@@ -317,7 +323,7 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
                     f"propagation, N={n_global}, nnz={nnz_global} (incl. self-loops), F={Fg}",
         "config": cfg,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel,
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_measured_this_run": False, "kernel": kernel,
                      "launches_per_step": len(events) // max(steps, 1), "avg_launch_ms": round(hop_ms, 4),
                      "algorithmic_bytes_per_launch": round(algo),
                      "gather_model_GBs": round(b_gather_bytes(nnz, n_local, F) / (hop_ms * 1e-3) / 1e9, 1) if durs_ms else 0.0},
@@ -454,17 +460,12 @@ def main():
 
     extras = []
     run_extras = args.extras != "none" and args.workload == "reddit" and args.graph == "config"
-    import threading
-
-    def give_up():
-        # ONE JSON line is printed.  Nothing after the first measurement may lose it: if the rest overruns its budget by
-        # two minutes (a hung collective, a rank that died), rank 0 prints the line with what it has and every rank leaves.
-        if rank0(ctx):
-            emit(out, extras + [{"aborted": "the remaining workloads overran their time budget"}], world)
-        os._exit(0)
-
-    watchdog = threading.Timer(max(1.0, args.extras_budget_s + 120.0 - (time.time() - t_start)) + (0 if rank0(ctx) else 5), give_up)
-    watchdog.daemon = True
+    # ONE JSON line is printed.  Nothing after the first measurement may lose it: if the rest overruns its budget by two
+    # minutes (a hung collective, a rank that died), rank 0 prints the line with what it has -- marked "aborted" -- and
+    # EVERY rank leaves with WATCHDOG_EXIT_CODE: a hang never ends with status 0.
+    watchdog = arm_watchdog(max(1.0, args.extras_budget_s + 120.0 - (time.time() - t_start)) + (0 if rank0(ctx) else 5),
+                            lambda: emit(dict(out, aborted=True), extras + [{"aborted": "the remaining workloads overran their time budget"}], world)
+                            if rank0(ctx) else None, start=False)
     if world > 1 or run_extras:
         watchdog.start()
     if run_extras:
@@ -479,9 +480,11 @@ def main():
             # one stays in this list -- then the strong-scaling graphs.
             if args.partition == "auto" and head.get("partition") == "features":
                 plan += [("headline", args.graph, "rows")]
+            # BASELINE configs[2] (products, row-partitioned) and configs[4] (papers100M-shaped, halo exchange over xGMI) are
+            # ALWAYS reported under the row partition as named entries, whichever partition wins a headline
             plan += [("products", "config", "rows"), ("products", "community", "rows")]
             if world == 8 or args.extras == "all":
-                plan += [("papers100M", "community", "rows")]
+                plan += [("papers100M", "community", "rows"), ("papers100M", "config", "rows")]
         else:
             plan += [("scorer", "", None)]
         for name, graph, part in plan:
@@ -507,6 +510,8 @@ def main():
                 else:
                     r = run_spmm(ctx, name, graph, args.steps, args.warmup, partition=part)
                     r["unit"] = "edges*feat/s"
+                    if part == "rows" and name in BASELINE_CONFIG:
+                        r["baseline_config"] = BASELINE_CONFIG[name]
             except Exception as e:       # reported, never hidden; at N > 1 the other ranks meet the watchdog
                 r = {"workload": f"{name} ({graph})", "failed": f"{type(e).__name__}: {e}"[:400]}
                 extras.append(r)
@@ -519,6 +524,30 @@ def main():
         emit(out, extras, world)
     if world > 1:
         dist.destroy_process_group()
+
+
+WATCHDOG_EXIT_CODE = 3
+
+
+def arm_watchdog(seconds: float, on_fire, start: bool = True):
+    """Timer that, when it fires, runs ``on_fire()`` (rank 0: print the line with what has been measured, marked
+    "aborted") and then ends the process with WATCHDOG_EXIT_CODE (non-zero: the launcher and the driver must see that
+    the run did not finish; os._exit because a hung collective cannot be unwound).  cancel() it when the work is done."""
+    import threading
+
+    def fire():
+        try:
+            on_fire()
+        finally:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(WATCHDOG_EXIT_CODE)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    if start:
+        t.start()
+    return t
 
 
 def rank0(ctx: Ctx) -> bool:
@@ -544,6 +573,11 @@ def compact_extra(e: dict) -> dict:
         out["row_order"] = "locality"
     if "note" in e:
         out["note"] = e["note"]
+    if "baseline_config" in e:
+        out["cfg"] = e["baseline_config"]
+        halo = c.get("halo", {})
+        if "exposed_exchange_ms_per_hop" in halo:
+            out["exposed_xchg_ms"] = halo["exposed_exchange_ms_per_hop"]
     return out
 
 

@@ -23,6 +23,7 @@ struct Tuning {
   int row_cols = 0;   // column block of the plain row kernel: 0 = auto (128 floats under a group-major schedule, else one pass up to 1280), -1 = never block, > 0 = that many floats
   int narrow_groups = 1;   // 0 = never use the 4- / 8-lane row groups (rows of <= 8 float4)
   int stream_u = 0;   // sweep_mode 4: gathers in flight per wave (0 = 8; 12 / 16: experiments)
+  int stream_lead = 0;  // sweep_mode 4: window steps a wave may run ahead of its XCD group (0 = 2; < 0: no pacing)
   int xcd_map = -1;   // k_spmm_rows workgroup order: -1 = what the schedule says (info->xcd_run); 0 = off; 1 = each XCD walks one contiguous eighth of the row order; S > 1 = runs of S rows dealt to the XCDs in turn
 };
 

@@ -231,6 +231,7 @@ extern "C" int disco_set_tuning(const char* key, int64_t value) {
   else if (!strcmp(key, "addr24")) t.addr24 = (int)value;
   else if (!strcmp(key, "xcd_map")) t.xcd_map = (int)value;
   else if (!strcmp(key, "stream_u")) t.stream_u = (int)value;
+  else if (!strcmp(key, "stream_lead")) t.stream_lead = (int)value;
   else if (!strcmp(key, "row_cols")) t.row_cols = (int)value;
   else if (!strcmp(key, "narrow_groups")) t.narrow_groups = (int)value;
   else if (!strcmp(key, "psync_pct")) t.psync_pct = (int)value;

@@ -576,12 +576,12 @@ static int launch_pairs(const char* w, const ScorerWs& L, int64_t i0, int64_t i1
   int64_t blocks = tiles < resident ? tiles : resident;
   if (blocks < 1) return DISCO_OK;
   const size_t lds_bytes = (size_t)(2 * 64 * (H + 4) + 2 * 8 * 64) * sizeof(float);
-  static bool attr_set = false;      // per instantiation: raised once, not on every launch
-  if (!attr_set) {
+  // the dynamic LDS limit is a per-DEVICE attribute of the kernel: raised on every call (microseconds against a kernel
+  // that runs for hundreds of milliseconds) rather than remembered in a process-wide flag that a second GPU would skip
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scorer_pairs<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes);
     if (e != hipSuccess) { set_last_hip_error((int)e); return DISCO_EHIP; }
-    attr_set = true;
   }
   hipLaunchKernelGGL((k_scorer_pairs<H>), dim3((unsigned)blocks), dim3(512), lds_bytes, s,
                      reinterpret_cast<const float*>(w + L.off_u), reinterpret_cast<const float*>(w + L.off_v),
@@ -640,12 +640,12 @@ static int launch_edges(const char* w, const ScorerWs& L, int64_t n, float thr, 
   int64_t blocks = n_pairs < resident ? n_pairs : resident;
   if (blocks < 1) return DISCO_OK;
   const size_t lds_bytes = (size_t)(2 * 64 * (H + 4) + 2 * 8 * 64) * sizeof(float);
-  static bool attr_set = false;      // per instantiation: the dynamic LDS limit is raised once, not on every launch
-  if (!attr_set) {
+  // the dynamic LDS limit is a per-DEVICE attribute of the kernel: raised on every call (microseconds against a kernel
+  // that runs for hundreds of milliseconds) rather than remembered in a process-wide flag that a second GPU would skip
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scorer_edges<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes);
     if (e != hipSuccess) { set_last_hip_error((int)e); return DISCO_EHIP; }
-    attr_set = true;
   }
   hipLaunchKernelGGL((k_scorer_edges<H>), dim3((unsigned)blocks), dim3(512), lds_bytes, s,
                      reinterpret_cast<const float*>(w + L.off_u), reinterpret_cast<const float*>(w + L.off_v),

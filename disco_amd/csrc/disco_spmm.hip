@@ -924,10 +924,16 @@ static void* g_scratch_ptr[kMaxDevices];   // per device: address of that device
 // Device address of this device's scratch array.  In host code the name `scratch` is only a stand-in for the
 // symbol, never an address: it is resolved ONCE per device with that device current, and everything afterwards
 // (kernel arguments) uses the returned pointer.
-static int scratch_for_current_device(void** out) {
+static int scratch_for_current_device(void** out, hipStream_t stream) {
   int dev = -1;
   DISCO_HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices) return DISCO_EUNSUPPORTED;
+  if (stream) {
+    // the array is per device: a stream of ANOTHER GPU would hand its kernels this GPU's scratch address
+    hipDevice_t sdev = -1;
+    DISCO_HIP_TRY(hipStreamGetDevice(stream, &sdev));
+    if ((int)sdev != dev) return DISCO_EINVAL;
+  }
   void* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
   if (!p) {
     DISCO_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
@@ -946,7 +952,7 @@ extern "C" int disco_spmm_csr_f32_noalloc(const int64_t* rowptr, const int32_t* 
   if (need > (size_t)DISCO_NOALLOC_SCRATCH_BYTES) return DISCO_ESCRATCH;
   void* ws = nullptr;
   if (need) {
-    int rc = scratch_for_current_device(&ws);
+    int rc = scratch_for_current_device(&ws, static_cast<hipStream_t>(stream));
     if (rc != DISCO_OK) return rc;
   }
   // Same kernels as disco_spmm_csr_f32.  Nothing in the scratch has to start at zero: every piece writes its whole

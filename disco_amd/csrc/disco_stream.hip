@@ -299,10 +299,10 @@ static int launch_stream_t(const StreamArgs& a) {
                                      (size_t)(P + 1) * s.sweep_count_padded * sizeof(uint32_t));
   DISCO_HIP_TRY(hipMemsetAsync(prog, 0, prog_bytes, a.stream));
   const int cap = tuning().psync_polls > 0 ? tuning().psync_polls : 64;
-  const int members = tuning().psync_pct < 0 ? 0 : (int)(blocks / PSYNC_GROUPS);     // psync_pct < 0: no pacing
+  const int members = tuning().stream_lead < 0 ? 0 : (int)(blocks / PSYNC_GROUPS);     // stream_lead < 0: no pacing
   hipLaunchKernelGGL((k_spmm_stream<HASVAL, U>), dim3((unsigned)blocks), dim3(256), lds_bytes, a.stream, a.rowptr, a.col, a.val,
                      a.x, a.ldx, a.y, a.ldy, a.nvec, a.perm, a.first, a.count, wptr, s.sweep_count_padded, P, a.flags, n_iter,
-                     prog, members, cap, a.fcols, tuning().psync_pct > 0 ? tuning().psync_pct : 2);
+                     prog, members, cap, a.fcols, tuning().stream_lead > 0 ? tuning().stream_lead : 2);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
 }

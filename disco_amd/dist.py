@@ -16,7 +16,6 @@ the CPU (gloo) tests can check the partition / exchange logic against the oracle
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass, field  # noqa: F401
 from typing import Callable, List, Optional
 
@@ -95,8 +94,6 @@ class RowPartition:
         need = torch.unique(hcol)                                 # sorted global ids this rank needs
         self.n_halo = int(need.numel())
         self.halo_nnz = int(hcol.numel())
-        if os.environ.get("DISCO_DENSE_HALO") == "1":
-            exchange = "dense"
         if exchange == "auto":
             vote = torch.tensor([1 if self.n_halo * 2 > self.n_global - self.n_local else 0], dtype=torch.int64,
                                 device=dev if world > 1 and dist.get_backend(group) != "gloo" else "cpu")
@@ -106,6 +103,11 @@ class RowPartition:
         self.dense = world > 1 and exchange == "dense"
         self._spmm = spmm_fn
         self._send_buf = self._recv_buf = self._full_buf = self._mine_buf = None
+        self._dense_key = None
+        # (before, after) event pairs around every wait for the exchange, recorded on the compute stream when
+        # `time_waits` is set: their elapsed time is the part of the transfer that compute did NOT cover
+        self.time_waits = False
+        self.wait_events: List[tuple] = []
         bounds = torch.tensor(col_offsets, device=dev, dtype=torch.int64)
         if self.dense:
             # halo block over the all-gathered table: shard g sits at rows [g * per, g * per + size_g)
@@ -191,7 +193,8 @@ class RowPartition:
         column still gets interior first, halo second: the bits do not depend on the chunking."""
         F, n = x.shape[1], self.n_local
         chunks = self._col_chunks(F)
-        if self._full_buf is None or self._full_buf[0].shape[1] != chunks[0][1] - chunks[0][0] or len(self._full_buf) != len(chunks):
+        if self._dense_key != (F, len(chunks), x.dtype, x.device):
+            self._dense_key = (F, len(chunks), x.dtype, x.device)
             self._full_buf = [torch.empty((self.world * self.per, self._xld(c1 - c0)), dtype=x.dtype, device=x.device) for c0, c1 in chunks]
             self._mine_buf = [torch.zeros((self.per, self._xld(c1 - c0)), dtype=x.dtype, device=x.device) for c0, c1 in chunks]
         works = []
@@ -200,10 +203,30 @@ class RowPartition:
             works.append(_all_gather_into(full.reshape(-1), mine.reshape(-1), self.group, async_op=True))
         self._spmm_call(self.adj_int, x, "sum", out)              # overlaps with the transfers
         for (c0, c1), full, work in zip(chunks, self._full_buf, works):
-            if work is not None:
-                work.wait()
+            self._wait(work, x)
             if self.adj_halo.nnz():
                 self._spmm_call(self.adj_halo, full[:, :c1 - c0], "sum_acc", out[:, c0:c1])
+        return out
+
+    def _wait(self, work, x: torch.Tensor) -> None:
+        """Make the compute stream wait for an exchange; with `time_waits` the wait is bracketed by two events on the
+        compute stream (exposed exchange time = what the interior SpMM did not cover)."""
+        if work is None:
+            return
+        if self.time_waits and x.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            work.wait()
+            e1.record()
+            self.wait_events.append((e0, e1))
+        else:
+            work.wait()
+
+    def exposed_wait_ms(self, clear: bool = True) -> List[float]:
+        """Elapsed ms of every recorded wait (call after a synchronize)."""
+        out = [a.elapsed_time(b) for a, b in self.wait_events]
+        if clear:
+            self.wait_events = []
         return out
 
     def spmm(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
@@ -212,8 +235,7 @@ class RowPartition:
             return self._spmm_dense(x, out)
         work, recv = self.start_exchange(x)
         self._spmm_call(self.adj_int, x, "sum", out)              # overlaps with the exchange
-        if work is not None:
-            work.wait()
+        self._wait(work, x)
         if self.n_halo:
             self._spmm_call(self.adj_halo, recv, "sum_acc", out)
         return out

@@ -1,9 +1,10 @@
 """Callers of the propagation path with the reference's interface
 (/root/reference/models/basicgnn_large.py:27-512): ``BasicGNN`` and ``GCN / GraphSAGE / GIN / SGC / JKNet``.
 
-Only what sits between the drivers and the convolutions is reproduced: the layer loop
-(``forward`` :161-207), ``predict`` (:222-233) and the loader-driven ``inference`` / ``large_inference``
-(:235-318).  Convolutions are the HIP-backed ones of ``disco_amd.models.convs_large``; dense layers,
+Only what sits between the drivers and the convolutions is provided: the layer loop
+(``forward`` :161-207), ``predict`` (:222-233) and the loader-driven ``forward_sampler`` / ``inference`` /
+``large_inference`` (:209-220, :235-318), the last three written from their interface contract (loader protocol,
+slice-after-propagate, where ``lin`` applies) around one shared per-depth step.  Convolutions are the HIP-backed ones of ``disco_amd.models.convs_large``; dense layers,
 BatchNorm, dropout and log_softmax are stock torch (already rocBLAS / MIOpen).  state_dict keys follow
 the reference (``convs.{i}.lin.weight``, ``convs.{i}.bias``, ``norms.{i}.*``, ``lin.*``).
 
@@ -175,74 +176,78 @@ class BasicGNN(torch.nn.Module):
         return F.log_softmax(x, dim=1)
 
     def forward_sampler(self, x, adjs):
-        # basicgnn_large.py:209-220
-        if not self.sgc:
-            for i, (adj, _, size) in enumerate(adjs):
-                x = self.convs[i](x, adj)
-                if i != self.nlayers - 1:
-                    x = self.norms[i](x)
-                    x = self.act(x)
-                    x = F.dropout(x, self.dropout, training=self.training)
+        """Training-time forward over sampled neighbourhoods (reference interface: basicgnn_large.py:209-220).
+        ``adjs`` holds one hop per entry, outermost hop first; a hop is an ``(adj_t, e_id, size)`` triple whose first
+        member is the bipartite adjacency (targets x sources) that the convolution of that depth consumes.  SGC has a
+        single K-hop convolution which walks the hops itself.  Hidden layers are followed by norm, activation and
+        dropout; the result is log-probabilities."""
+        if self.sgc:
+            h = self.convs[0].forward_sampler(x, adjs)
         else:
-            x = self.convs[0].forward_sampler(x, adjs)
-        return F.log_softmax(x, dim=1)
+            h, last = x, self.nlayers - 1
+            for depth, hop in enumerate(adjs):
+                h = self.convs[depth](h, hop[0])
+                if depth < last:
+                    if self.norms is not None:
+                        h = self.norms[depth](h)
+                    if self.act is not None:
+                        h = self.act(h)
+                    h = F.dropout(h, self.dropout, training=self.training)
+        return F.log_softmax(h, dim=1)
 
     @torch.no_grad()
     def predict(self, x: Tensor, edge_index, *, edge_weight: Optional[Tensor] = None, edge_attr=None) -> Tensor:
         self.eval()
         return self.forward(x, edge_index, edge_weight=edge_weight, edge_attr=edge_attr)
 
+    def _sampled_layer(self, depth: int, x: Tensor, adj_t, keep: int, raw_final: bool) -> Tensor:
+        """One depth of sampled evaluation on a bipartite block whose first ``keep`` output rows are the targets
+        (NeighborSampler puts a batch's targets first): propagate, THEN slice.
+          SGC      : hop ``depth`` of the K-hop convolution; its ``lin`` is applied once, after the last hop;
+          otherwise: convolution ``depth``; hidden layers get act / norm; the final layer stays raw unless a
+                     jumping-knowledge head exists and the caller wants it applied (``raw_final`` False)."""
+        if self.sgc:
+            conv = self.convs[0]
+            h = conv.propagate(adj_t, x=x)[:keep]
+            return conv.lin(h) if depth == self.temp_layers - 1 else h
+        h = self.convs[depth](x, adj_t)[:keep]
+        final = depth == self.nlayers - 1
+        if final and raw_final:
+            return h
+        h = self._post(h, depth)
+        return self.lin(h) if final and hasattr(self, "lin") else h
+
     @torch.no_grad()
     def inference(self, x_all: Tensor, loader, device=None, progress_bar: bool = False) -> Tensor:
-        """Layer-wise sampled inference (basicgnn_large.py:235-281).  `loader` yields
-        ``(batch_size, n_id, adj)`` with ``adj.adj_t`` a bipartite adjacency (any object this package's
-        convolutions accept)."""
+        """Layer-wise sampled evaluation (reference interface: basicgnn_large.py:235-281).  The loader is walked once
+        per depth and yields ``(batch_size, n_id, block)`` with ``block.adj_t`` the batch's bipartite adjacency; every
+        pass maps the features of ALL nodes to the next depth, batch by batch (outputs collected on the host in loader
+        order, which must cover the nodes in order), so no depth ever needs more than one batch on the device."""
         self.eval()
         assert self.jk_mode is None or self.jk_mode == "last"
-        for i in range(self.temp_layers):
-            xs: List[Tensor] = []
-            for batch_size, n_id, adj in loader:
-                x = x_all[n_id].to(device)
-                edge_index = adj.adj_t.to(device)
-                if not self.sgc:
-                    x = self.convs[i](x, edge_index)[:batch_size]
-                    if i == self.nlayers - 1 and self.jk_mode is None:
-                        xs.append(x.cpu())
-                        continue
-                    x = self._post(x, i)
-                    if i == self.nlayers - 1 and hasattr(self, "lin"):
-                        x = self.lin(x)
-                else:
-                    x = self.convs[0].propagate(edge_index, x=x)[:batch_size]
-                    if i == self.temp_layers - 1:
-                        x = self.convs[0].lin(x)
-                xs.append(x.cpu())
-            x_all = torch.cat(xs, dim=0)
-        return F.log_softmax(x_all, dim=1).to(device)
+        feats = x_all
+        for depth in range(self.temp_layers):
+            feats = torch.cat([self._sampled_layer(depth, feats[n_id].to(device), block.adj_t.to(device), batch_size,
+                                                   raw_final=self.jk_mode is None).cpu()
+                               for batch_size, n_id, block in loader], dim=0)
+        return F.log_softmax(feats, dim=1).to(device)
 
     @torch.no_grad()
     def large_inference(self, x_all, loader, device=None, progress_bar: bool = False) -> Tensor:
-        """Batch-wise sampled inference (basicgnn_large.py:283-318); `loader` yields
-        ``(batch_size, n_id, adjs)`` with one ``(adj_t, e_id, size)``-like entry per layer."""
+        """Batch-wise sampled evaluation (reference interface: basicgnn_large.py:283-318).  The loader yields
+        ``(batch_size, n_id, blocks)`` with one ``(adj_t, e_id, size)`` block per depth; ``size[1]`` is the number of
+        target rows of that block.  A batch runs through every depth on the device and only its final rows return to
+        the host; the final layer's output is left raw (no head), as the reference does on this route."""
         self.eval()
         assert self.jk_mode is None or self.jk_mode == "last"
-        xs: List[Tensor] = []
-        for batch_size, n_id, adjs in loader:
-            x = torch.as_tensor(x_all[n_id], dtype=torch.float32).to(device)
-            for i in range(self.temp_layers):
-                target_num = adjs[i][2][1]
-                edge_index = adjs[i].adj_t.to(device)
-                if not self.sgc:
-                    x = self.convs[i](x, edge_index)[:target_num]
-                    if i == self.nlayers - 1:
-                        continue
-                    x = self._post(x, i)
-                else:
-                    x = self.convs[0].propagate(edge_index, x=x)[:target_num]
-                    if i == self.temp_layers - 1:
-                        x = self.convs[0].lin(x)
-            xs.append(x.cpu())
-        return F.log_softmax(torch.cat(xs, dim=0), dim=1)
+        outs: List[Tensor] = []
+        for _batch_size, n_id, blocks in loader:
+            h = torch.as_tensor(x_all[n_id], dtype=torch.float32).to(device)
+            for depth in range(self.temp_layers):
+                block = blocks[depth]
+                h = self._sampled_layer(depth, h, block.adj_t.to(device), int(block[2][1]), raw_final=True)
+            outs.append(h.cpu())
+        return F.log_softmax(torch.cat(outs, dim=0), dim=1)
 
     @torch.no_grad()
     def full_inference(self, x: Tensor, adj_t) -> Tensor:

@@ -160,6 +160,8 @@ int disco_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* v
  *     (n_hub_partials * roundup(F, 4) * 4 bytes; e.g. 6898 partial rows at F = 602) -- nothing is launched then;
  *   - calls no hipMalloc / hipFree / allocating routine.  The first call on each device resolves the array's
  *     device address (hipGetSymbolAddress): make that call once outside any capture;
+ *   - the CURRENT device must be the device `stream` belongs to (the array is per device; DISCO_EINVAL otherwise);
+ *   - graph capture: tests/test_zz_no_alloc.py captures a K-hop of these calls in a HIP graph and replays it;
  *   - all calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams) race on the
  *     hub rows' partial sums.  Calls on one stream, or on different GPUs, are safe. */
 #define DISCO_NOALLOC_SCRATCH_BYTES (16u << 20)
@@ -277,7 +279,8 @@ int disco_sym_threshold_fill(const float* S, int64_t n, int64_t lds, float thres
  * S > 1 = runs of S rows), "row_cols" (column block of the plain row kernel: 0 = 128 floats under a group-major
  * schedule and one pass otherwise, -1 = never block, > 0 = that width), "narrow_groups" (0 = no 4- / 8-lane row groups),
  * "win_cols" (column block of modes 2/3, default 128), "win_rpg" (rows per lane group and launch, 1 or 2),
- * "sweep_blocks_per_cu", "psync_pct", "psync_polls" (mode 3 pacing), "addr24" (0 = always 64-bit gather
+ * "sweep_blocks_per_cu", "psync_pct", "psync_polls" (mode 3 pacing), "stream_lead" (mode 4: window steps a wave may run
+ * ahead of its XCD group; < 0 = no pacing), "addr24" (0 = always 64-bit gather
  * addresses).  Unknown keys return DISCO_EINVAL. */
 int disco_set_tuning(const char* key, int64_t value);
 

@@ -122,7 +122,7 @@ def test_global_graph_partition_khop(world, K, comm, mu, tmp_path):
     entries and the dense exchange; community graph -> about mu * (world-1)/world and the need-only exchange."""
     from disco_amd import graphgen
     mp.spawn(_global_worker, args=(world, _free_port(), K, comm, mu, str(tmp_path)), nprocs=world, join=True)
-    parts = [torch.load(tmp_path / f"g{r}.pt", weights_only=False) for r in range(world)]
+    parts = [torch.load(tmp_path / f"g{r}.pt", weights_only=True) for r in range(world)]
     n, nnz = 1201, 14000
     norm_adj = comm > 0
     # the same global graph, generated block pair by block pair in one process

@@ -20,7 +20,8 @@ def _case(n, cols, n_c, k, seed, repeats=True):
     anchor = rng.integers(0, n, (n_c, k), dtype=np.int64)
     if repeats and n_c > 2:
         anchor[0, :] = anchor[0, 0]            # the same anchor three times
-        anchor[1, 1] = anchor[1, 0]
+        if k > 1:
+            anchor[1, 1] = anchor[1, 0]
     return T, anchor
 
 

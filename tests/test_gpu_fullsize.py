@@ -1,0 +1,176 @@
+"""The two BASELINE configurations that no checker had seen at their real size (round-2 verdict, item 1):
+
+  configs[4]  ogbn-papers100M-shaped graph, FULL size on one GPU at its own width F = 128
+              (N = 111 059 956, nnz = 1 615 685 872, gcn_norm(add_self_loops=False) as LargeScaleCondensing_Sampled.py:491);
+  configs[2]  ogbn-products-shaped graph ROW-PARTITIONED at full size (two ranks sharing the test box's GPU, both exchange
+              modes of dist.RowPartition, halo rows staged over gloo because RCCL refuses two ranks on one device).
+
+Sizes the oracle cannot finish in seconds are checked through size-independent properties (exact entry count, A*1 = row sums,
+K = 2 = two hops) plus row samples against the float64 oracle restricted to the rows the sample touches."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import RTOL, assert_fwd_close
+from test_dist_cpu import _free_port
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _sub_csr(rowptr, col32, val, rows):
+    """CSR of the given rows (device tensors) with the columns renumbered to the distinct columns they touch."""
+    beg, end = rowptr[rows], rowptr[rows + 1]
+    cnt = end - beg
+    sub_rp = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=rowptr.device)
+    torch.cumsum(cnt, 0, out=sub_rp[1:])
+    idx = torch.repeat_interleave(beg - sub_rp[:-1], cnt) + torch.arange(int(sub_rp[-1]), device=rowptr.device)
+    uniq, inv = torch.unique(col32[idx].to(torch.int64), return_inverse=True)
+    a = sp.csr_matrix((val[idx].double().cpu().numpy(), inv.cpu().numpy(), sub_rp.cpu().numpy()), shape=(rows.numel(), uniq.numel()))
+    return a, uniq
+
+
+def oracle_khop_rows(rowptr, col32, val, x_rows_fn, rows, K):
+    """float64 A^K x restricted to `rows` (and the forward-error scale |A|^K |x|): the oracle's CSR product applied to
+    the K-level neighbourhood of the sample only.  x_rows_fn(ids) returns the float32 rows of x as a numpy array."""
+    if K == 0:
+        xr = x_rows_fn(rows).astype(np.float64)
+        return xr, np.abs(xr)
+    a, uniq = _sub_csr(rowptr, col32, val, rows)
+    y_in, b_in = oracle_khop_rows(rowptr, col32, val, x_rows_fn, uniq, K - 1)
+    return a @ y_in, abs(a) @ b_in
+
+
+@pytest.mark.timeout(900)
+def test_papers100m_shaped_full_size_one_gpu_f128():
+    from disco_amd import SparseTensor, graphgen, ops, utils
+    torch.cuda.empty_cache()
+    spec = graphgen.SPECS["papers100M"]
+    n, F, K = spec.n_nodes, spec.feat, 2
+    assert (n, spec.nnz, F) == (111_059_956, 1_615_685_872, 128)
+    dev = torch.device(DEV)
+    row, col = graphgen.powerlaw_edges(n, spec.nnz, spec.skew, spec.seed, device=dev)
+    assert row.numel() == spec.nnz, "exact entry count (no self-loops: gcn_norm(add_self_loops=False))"
+    adj = SparseTensor(row=row, col=col, value=None, sparse_sizes=(n, n), is_sorted=True)
+    # A1 at full size: utils.gcn_norm(edge_index, None, n, add_self_loops=False) -- _Sampled.py:491
+    _, w = utils.gcn_norm(torch.stack([row, col]), None, n, add_self_loops=False)
+    deg = torch.bincount(col, minlength=n)
+    sel = torch.randint(0, spec.nnz, (1 << 20,), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    d64 = deg.double().pow(-0.5)
+    d64[torch.isinf(d64)] = 0
+    w64 = d64[row[sel]] * d64[col[sel]]
+    assert bool(((w[sel].double() - w64).abs() <= 2.5e-7 * w64).all()), "gcn_norm weights (sample of 2^20 entries)"
+    del row, col, sel, d64, w64, deg
+    adj = adj.set_value(w)
+    del w
+    torch.cuda.empty_cache()
+    assert adj.nnz() == spec.nnz and adj.storage.rowptr().dtype == torch.int64
+    rp, c32, v = adj.storage.rowptr(), adj._col32, adj.storage.value()
+
+    # A * 1 == row sums (float64 prefix sums of the stored values)
+    cs = torch.cumsum(v.double(), 0)
+    cs = torch.cat([cs.new_zeros(1), cs])
+    rs = cs[rp[1:]] - cs[rp[:-1]]
+    del cs
+    a1 = ops.spmm_raw(adj, torch.ones(n, 4, device=dev), "sum")[:, 0].double()
+    assert bool(((a1 - rs).abs() <= 1e-5 * rs.abs() + 1e-9).all())
+    del a1, rs
+    torch.cuda.empty_cache()
+
+    x = graphgen.features(n, F, spec.seed, device=dev)                 # 56.9 GB
+    t = ops.spmm_raw(adj, x, "sum")                                    # hop 1
+    y2 = ops.spmm_raw(adj, t, "sum")                                   # hop 2 of "two hops"
+    rows = torch.from_numpy(np.sort(np.random.default_rng(3).choice(n, 1024, replace=False))).to(dev)
+    xr = lambda ids: x[ids].cpu().numpy()                              # noqa: E731
+    y64, bound = oracle_khop_rows(rp, c32, v, xr, rows, 1)
+    assert_fwd_close(t[rows].cpu().numpy(), y64, bound, what="papers100M full size, hop 1, 1024-row sample")
+    # hop 2 against the oracle applied to the device's own hop-1 result (the 2-level neighbourhood of a sample reaches
+    # the multi-million-entry hub rows of this graph; hop 1 is pinned above, so the two together pin K = 2)
+    rows_b = torch.from_numpy(np.sort(np.random.default_rng(4).choice(n, 1024, replace=False))).to(dev)
+    y64, bound = oracle_khop_rows(rp, c32, v, lambda ids: t[ids].cpu().numpy(), rows_b, 1)
+    assert_fwd_close(y2[rows_b].cpu().numpy(), y64, bound, rtol=RTOL, what="papers100M full size, hop 2, 1024-row sample")
+    # K = 2 through disco_khop_csr_f32 == two hops, bit for bit: hop 1 lands in the scratch buffer (t is re-used as
+    # scratch: 4 x 57 GB of operands do not fit next to the graph), so compare against copies of a 2^21-row sample
+    # and the float64 column sums of everything
+    pick = torch.randint(0, n, (1 << 21,), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    y2_rows, y2_sum = y2[pick].clone(), y2.sum(dim=0, dtype=torch.float64)
+    t_rows = t[pick].clone()
+    del y2
+    torch.cuda.empty_cache()
+    yk = ops.khop(adj, x, K, scratch=t.reshape(-1))
+    assert torch.equal(yk[pick], y2_rows) and torch.equal(yk.sum(dim=0, dtype=torch.float64), y2_sum)
+    assert torch.equal(t[pick], t_rows), "the intermediate hop in the scratch buffer"
+    assert bool(torch.isfinite(y2_sum).all())
+
+
+# ---- configs[2]: products, row-partitioned at full size -------------------------------------------------------------
+def _products_worker(rank, world, port, exchange, sample_seed, n_sample, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disco_amd import graphgen
+        from disco_amd.dist import build_partitioned_graph
+        spec = graphgen.SPECS["products"]
+        dev = torch.device(DEV)
+        F, K = spec.feat, 2
+        g = build_partitioned_graph(spec.n_nodes, spec.nnz, F, spec.skew, spec.seed, spec.norm, world, rank, dev, 128,
+                                    exchange=exchange, K=K)
+        assert g.part.dense == (exchange == "dense")
+        y = g.khop(K)
+        torch.cuda.synchronize()
+        lo, hi = g.part.col_offsets[rank], g.part.col_offsets[rank + 1]
+        rows = np.sort(np.random.default_rng(sample_seed).choice(spec.n_nodes, n_sample, replace=False))
+        mine = rows[(rows >= lo) & (rows < hi)]
+        np.save(os.path.join(result_dir, f"y_{exchange}_{rank}.npy"), y[torch.from_numpy(mine - lo).to(dev)].cpu().numpy())
+        np.save(os.path.join(result_dir, f"meta_{exchange}_{rank}.npy"),
+                np.array([g.nnz_local, g.nnz_global, g.part.n_halo, g.part.halo_nnz, lo, hi, float(y.double().abs().sum())]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_products_shaped_row_partitioned_at_full_size(tmp_path):
+    """BASELINE configs[2]: N = 2 449 029, nnz = 61 859 140 (+ N self-loops), F = 100, K = 2, 1-D row partition over two
+    ranks through dist.build_partitioned_graph (what bench.py runs at N > 1), need-only and dense exchange.  The assembled
+    rows of a 2048-row sample meet the forward-error bar against the float64 oracle on the GLOBAL matrix (rebuilt here
+    from both ranks' generators), and the two exchange modes agree bit for bit."""
+    from disco_amd import SparseTensor, graphgen
+    spec = graphgen.SPECS["products"]
+    n, F, K, world, n_sample = spec.n_nodes, spec.feat, 2, 2, 2048
+    for exchange in ("need", "dense"):
+        mp.spawn(_products_worker, args=(world, _free_port(), exchange, 17, n_sample, str(tmp_path)), nprocs=world, join=True)
+    dev = torch.device(DEV)
+    # the global matrix, normalised as build_partitioned_graph does for "normalize_adj" (+I, row degree, float64, one rounding)
+    rows_g, cols_g, xs = [], [], []
+    for r in range(world):
+        row, col, offs = graphgen.partition_edges(n, spec.nnz, spec.skew, spec.seed, world, r, dev, add_diag=True)
+        rows_g.append(row + offs[r])
+        cols_g.append(col)
+        xs.append(graphgen.features(offs[r + 1] - offs[r], F, spec.seed + 31 * r, device=dev))
+    row, col = torch.cat(rows_g), torch.cat(cols_g)
+    del rows_g, cols_g
+    assert row.numel() == spec.nnz + n
+    cnt = torch.bincount(row, minlength=n)
+    r64 = cnt.double().pow(-0.5)
+    val = (r64[row] * r64[col]).to(torch.float32)
+    adj = SparseTensor(row=row, col=col, value=val, sparse_sizes=(n, n), is_sorted=True)
+    x = torch.cat(xs)
+    del xs, row, col, val
+    rows = np.sort(np.random.default_rng(17).choice(n, n_sample, replace=False))
+    rows_d = torch.from_numpy(rows).to(dev)
+    y64, bound = oracle_khop_rows(adj.storage.rowptr(), adj._col32, adj.storage.value(), lambda ids: x[ids].cpu().numpy(), rows_d, K)
+    got = {}
+    for exchange in ("need", "dense"):
+        metas = [np.load(tmp_path / f"meta_{exchange}_{r}.npy") for r in range(world)]
+        assert sum(int(m[0]) for m in metas) == int(metas[0][1]) == spec.nnz + n, "exact global entry count"
+        assert all(int(m[2]) > 0 and int(m[3]) > 0 for m in metas), "every rank has a halo on a graph without locality"
+        got[exchange] = np.concatenate([np.load(tmp_path / f"y_{exchange}_{r}.npy") for r in range(world)])
+        assert got[exchange].shape == (n_sample, F)
+        assert_fwd_close(got[exchange], y64, K * bound, what=f"products row-partitioned, exchange={exchange}")
+    assert np.array_equal(got["need"], got["dense"]), "interior first, halo second: the exchange mode does not change a bit"

@@ -461,12 +461,12 @@ def test_streaming_window_kernel_same_bits_as_plain(F, reduce, weighted):
     lib.disco_set_tuning(b"sweep_blocks_per_cu", 1)        # 256 workgroups x 4 waves x 8 rows < n: several sweeps
     try:
         y_s = run(win)
-        lib.disco_set_tuning(b"psync_pct", -1)            # same result without pacing
+        lib.disco_set_tuning(b"stream_lead", -1)            # same result without pacing
         y_u = run(win)
     finally:
         lib.disco_set_tuning(b"sweep_mode", 2)
         lib.disco_set_tuning(b"sweep_blocks_per_cu", 0)
-        lib.disco_set_tuning(b"psync_pct", 0)
+        lib.disco_set_tuning(b"stream_lead", 0)
     assert torch.equal(y_p, y_s) and torch.equal(y_p, y_u)
     assert bool((y_s[:, F:] == 7.0).all())
 
@@ -520,7 +520,7 @@ def test_full_size_properties_products_shaped():
     try:
         assert torch.equal(ops.spmm_raw(adj, x, "sum"), y)
     finally:
-        lib.disco_set_tuning(b"xcd_map", 0)
+        lib.disco_set_tuning(b"xcd_map", -1)       # the library default: info->xcd_run decides
     y2 = ops.khop(adj, x, 2)
     assert bool(torch.isfinite(y2).all())
 

@@ -3,7 +3,11 @@ import numpy as np
 import pytest
 import torch
 
+import json
 import os
+import subprocess
+import sys
+import time
 
 from helpers import ROOT, orc
 from disco_amd import SparseTensor, graphgen, ops
@@ -229,3 +233,29 @@ def test_bench_line_stays_short(capsys, tmp_path, monkeypatch):
     assert all(len(json.dumps(e)) < 260 for e in line["extra_workloads"])
     assert cap.err.startswith("BENCH_DETAIL ") and json.loads(cap.err[len("BENCH_DETAIL "):])["extra_workloads"][0] == extras[0]
     assert json.load(open(tmp_path / "gpurun_out" / "bench_detail_n8.json"))["value"] == full["value"]
+
+
+def test_bench_watchdog_prints_the_line_and_exits_nonzero(tmp_path):
+    """A hang (an extra workload that never returns: hung collective, dead rank) must not end with status 0: the
+    watchdog prints the ONE line with what has been measured, marked "aborted", and the process leaves with
+    bench.WATCHDOG_EXIT_CODE."""
+    script = tmp_path / "hang.py"
+    script.write_text(
+        "import importlib.util, sys, time\n"
+        f"spec = importlib.util.spec_from_file_location('bench_mod3', {os.path.join(ROOT, 'bench.py')!r})\n"
+        "bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)\n"
+        f"bench.ROOT = {str(tmp_path)!r}\n"
+        "out = {'metric': 'K-hop SpMM edges*feat/s', 'value': 1.0e12, 'n_gpus': 1, 'ms_per_step': 38.0}\n"
+        "extras = [{'workload': 'products', 'ms_per_step': 8.1, 'value': 1.5e12, 'roofline': {'frac': 0.07}}]\n"
+        "bench.arm_watchdog(0.3, lambda: bench.emit(dict(out, aborted=True), extras + [{'aborted': 'overran'}], 1))\n"
+        "time.sleep(60)          # the fake extra that sleeps past the budget\n"
+        "print('never reached')\n")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=50)
+    assert time.time() - t0 < 40
+    assert p.returncode == 3, p.stderr[-400:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and "never reached" not in p.stdout
+    line = json.loads(lines[0])
+    assert line["aborted"] is True and line["value"] == 1.0e12
+    assert any("aborted" in e for e in line["extra_workloads"])

@@ -58,3 +58,58 @@ def test_noalloc_entry_rejects_oversized_problems():
     assert lib.disco_spmm_workspace_bytes(info, 602) > _lib.NOALLOC_SCRATCH_BYTES
     rc = lib.disco_spmm_csr_f32_noalloc(None, None, None, 10, None, 608, None, 608, 602, 0, None, info, None)
     assert rc == -5 and b"scratch" in lib.disco_status_string(rc)
+
+
+def test_noalloc_entry_under_hip_graph_capture():
+    """The header offers this entry point to code under HIP graph capture: capture a K = 2 propagation made of
+    disco_spmm_csr_f32_noalloc calls on a hub-bearing graph (first call made OUTSIDE the capture, as the header
+    demands: it resolves the scratch address), replay the graph twice -- the second time on new input values in
+    the same buffers -- and compare bits with the workspace entry point."""
+    from disco_amd import SparseTensor, _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    n, F, K = 5000, 256, 2
+    rowptr, col, val = random_csr(n, n, 14, seed=21, hubs=[(5, 40000), (77, 6000), (1234, 2100)], weighted=True)
+    val = (val * 0.05).astype(np.float32)
+    adj = SparseTensor(rowptr=torch.from_numpy(rowptr).to(dev), col=torch.from_numpy(col).to(dev),
+                       value=torch.from_numpy(val).to(dev), sparse_sizes=(n, n), is_sorted=True)
+    ws, info = adj.schedule(256, 1024)
+    assert info.n_hub_partials > 0 and info.n_multi_rows > 0
+    need = int(lib.disco_spmm_workspace_bytes(info, F))
+    assert 0 < need <= _lib.NOALLOC_SCRATCH_BYTES
+    x = torch.randn(n, F, device=dev)
+    t_ref, y_ref = torch.empty(n, F, device=dev), torch.empty(n, F, device=dev)
+    t_new, y_new = torch.zeros(n, F, device=dev), torch.zeros(n, F, device=dev)
+    sws = torch.empty(need, dtype=torch.uint8, device=dev)
+    csr = (adj._rowptr.data_ptr(), adj._col32.data_ptr(), adj._value.data_ptr(), n)
+
+    def khop_noalloc(stream):
+        _lib.check(lib.disco_spmm_csr_f32_noalloc(*csr, x.data_ptr(), F, t_new.data_ptr(), F, F, 0, ws.data_ptr(), info, stream), "hop 1")
+        _lib.check(lib.disco_spmm_csr_f32_noalloc(*csr, t_new.data_ptr(), F, y_new.data_ptr(), F, F, 0, ws.data_ptr(), info, stream), "hop 2")
+
+    def khop_ref():
+        s = _lib.current_stream(dev)
+        _lib.check(lib.disco_spmm_csr_f32(*csr, x.data_ptr(), F, t_ref.data_ptr(), F, F, 0, ws.data_ptr(), info, sws.data_ptr(), need, s), "ref 1")
+        _lib.check(lib.disco_spmm_csr_f32(*csr, t_ref.data_ptr(), F, y_ref.data_ptr(), F, F, 0, ws.data_ptr(), info, sws.data_ptr(), need, s), "ref 2")
+
+    khop_noalloc(_lib.current_stream(dev))          # outside any capture: resolves the scratch address of this device
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        free_before = torch.cuda.mem_get_info(dev)[0]
+        with torch.cuda.graph(graph, stream=side):
+            khop_noalloc(_lib.current_stream(dev))  # the capturing stream
+        assert torch.cuda.mem_get_info(dev)[0] >= free_before - (2 << 20), "capture of the allocation-free K-hop allocated device memory"
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for trial in range(2):
+        if trial:
+            x.copy_(torch.randn(n, F, device=dev))  # new values, same buffers: what a replayed graph sees
+        t_new.fill_(-1.0)
+        y_new.fill_(-1.0)
+        graph.replay()
+        khop_ref()
+        torch.cuda.synchronize()
+        assert torch.equal(t_new, t_ref) and torch.equal(y_new, y_ref), f"replay {trial}"
+        assert bool(torch.isfinite(y_new).all())
