@@ -23,6 +23,26 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _progress(msg):
+    """A line per stage into gpurun_out/ (and stdout): the GPU harness takes three silent minutes for a hang."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "test_progress.log"), "a") as fh:
+            fh.write(msg + "\n")
+    except OSError:
+        pass
+    print(msg, flush=True)
+
+
+def _colsum64(y, chunk=1 << 22):
+    """float64 column sums in row chunks (a float64 copy of a 57 GB operand does not fit); same chunks => same bits."""
+    tot = torch.zeros(y.shape[1], dtype=torch.float64, device=y.device)
+    for i in range(0, y.shape[0], chunk):
+        tot += y[i:i + chunk].sum(dim=0, dtype=torch.float64)
+    return tot
+
+
 def _sub_csr(rowptr, col32, val, rows):
     """CSR of the given rows (device tensors) with the columns renumbered to the distinct columns they touch."""
     beg, end = rowptr[rows], rowptr[rows + 1]
@@ -72,19 +92,33 @@ def test_papers100m_shaped_full_size_one_gpu_f128():
     assert adj.nnz() == spec.nnz and adj.storage.rowptr().dtype == torch.int64
     rp, c32, v = adj.storage.rowptr(), adj._col32, adj.storage.value()
 
-    # A * 1 == row sums (float64 prefix sums of the stored values)
-    cs = torch.cumsum(v.double(), 0)
-    cs = torch.cat([cs.new_zeros(1), cs])
-    rs = cs[rp[1:]] - cs[rp[:-1]]
+    # A * 1 == row sums (float64 segment sums of the stored values)
+    # per-row float64 sums from prefix sums over chunks of <= 2^27 entries cut at row boundaries (ONE prefix sum over
+    # 1.6e9 values loses 1e-8 absolute, more than a small row sum allows; torch.segment_reduce miscounts beyond 2^31
+    # entries; an index_add_ serialises its float64 atomics on the multi-million-entry hub rows)
+    rs = torch.empty(n, dtype=torch.float64, device=dev)
+    r0 = 0
+    while r0 < n:
+        e0 = int(rp[r0])
+        r1 = int(torch.searchsorted(rp, torch.tensor([e0 + (1 << 27)], device=dev)))
+        r1 = min(n, max(r1 - 1, r0 + 1))
+        e1 = int(rp[r1])
+        cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), torch.cumsum(v[e0:e1].double(), 0)])
+        rs[r0:r1] = cs[rp[r0 + 1:r1 + 1] - e0] - cs[rp[r0:r1] - e0]
+        r0 = r1
     del cs
+    _progress("papers100M full size: graph, gcn_norm and float64 row sums ready")
     a1 = ops.spmm_raw(adj, torch.ones(n, 4, device=dev), "sum")[:, 0].double()
     assert bool(((a1 - rs).abs() <= 1e-5 * rs.abs() + 1e-9).all())
     del a1, rs
     torch.cuda.empty_cache()
 
+    _progress("papers100M full size: A*1 == row sums ok")
     x = graphgen.features(n, F, spec.seed, device=dev)                 # 56.9 GB
     t = ops.spmm_raw(adj, x, "sum")                                    # hop 1
     y2 = ops.spmm_raw(adj, t, "sum")                                   # hop 2 of "two hops"
+    torch.cuda.synchronize()
+    _progress("papers100M full size: two hops at F = 128 done")
     rows = torch.from_numpy(np.sort(np.random.default_rng(3).choice(n, 1024, replace=False))).to(dev)
     xr = lambda ids: x[ids].cpu().numpy()                              # noqa: E731
     y64, bound = oracle_khop_rows(rp, c32, v, xr, rows, 1)
@@ -97,13 +131,14 @@ def test_papers100m_shaped_full_size_one_gpu_f128():
     # K = 2 through disco_khop_csr_f32 == two hops, bit for bit: hop 1 lands in the scratch buffer (t is re-used as
     # scratch: 4 x 57 GB of operands do not fit next to the graph), so compare against copies of a 2^21-row sample
     # and the float64 column sums of everything
+    _progress("papers100M full size: oracle row samples ok")
     pick = torch.randint(0, n, (1 << 21,), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
-    y2_rows, y2_sum = y2[pick].clone(), y2.sum(dim=0, dtype=torch.float64)
+    y2_rows, y2_sum = y2[pick].clone(), _colsum64(y2)
     t_rows = t[pick].clone()
     del y2
     torch.cuda.empty_cache()
     yk = ops.khop(adj, x, K, scratch=t.reshape(-1))
-    assert torch.equal(yk[pick], y2_rows) and torch.equal(yk.sum(dim=0, dtype=torch.float64), y2_sum)
+    assert torch.equal(yk[pick], y2_rows) and torch.equal(_colsum64(yk), y2_sum)
     assert torch.equal(t[pick], t_rows), "the intermediate hop in the scratch buffer"
     assert bool(torch.isfinite(y2_sum).all())
 
