@@ -50,9 +50,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="reddit", choices=["reddit", "arxiv", "products", "papers100M", "papers100M-shard"])
-    ap.add_argument("--graph", default="config", choices=["config", "community", "community-scrambled"],
+    ap.add_argument("--graph", default="config", choices=["config", "config-truncated", "community", "community-scrambled"],
                     help="generator variant (graphgen.py): locality-free configuration model [headline], LFR-style "
                          "communities in partitioner order, or the same behind a random relabelling (N = 1 only)")
+    ap.add_argument("--max-degree", type=int, default=0,
+                    help="truncate the head of the degree law: largest expected degree (0 = untruncated; --graph config-truncated "
+                         "uses graphgen.PRODUCTS_MAX_DEGREE)")
     ap.add_argument("--locality-max-group", type=int, default=8192, help="group size bound of --order locality (0: none)")
     ap.add_argument("--locality-sweeps", type=int, default=8, help="label-propagation sweeps of --order locality")
     ap.add_argument("--order", default="auto", choices=["auto", "degree", "locality"],
@@ -206,15 +209,17 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
     if partition == "features":
         ld = (F + args.slab_pad - 1) // args.slab_pad * args.slab_pad
     comm, mu = (graphgen.COMMUNITY_SIZE, graphgen.COMMUNITY_MU) if graph.startswith("community") else (0, 1.0)
+    max_deg = graphgen.PRODUCTS_MAX_DEGREE if graph == "config-truncated" else args.max_degree
     events = []
     t_setup = time.time()
     cfg = {"K": K, "F": Fg, "ld": ld, "skew": skew, "scale": args.scale,
-           "graph": {"config": "configuration model, no locality",
+           "graph": {"config": "configuration model, no locality" + (f", head truncated at expected degree {max_deg}" if max_deg else ""),
+                     "config-truncated": f"configuration model, no locality, head truncated at expected degree {max_deg}",
                      "community": f"LFR-style communities of {comm} nodes, mixing mu={mu}, partitioner order",
                      "community-scrambled": f"LFR-style communities of {comm} nodes, mixing mu={mu}, ids scrambled"}[graph]}
     if partition in ("single", "features"):
         row, col = graphgen.powerlaw_edges(n_global, nnz_target, skew, spec.seed, device=dev, comm_size=comm, mu=mu,
-                                           scramble=graph.endswith("scrambled"))
+                                           scramble=graph.endswith("scrambled"), max_degree=max_deg)
         adj = SparseTensor(row=row, col=col, value=None, sparse_sizes=(n_global, n_global), is_sorted=True)
         del row, col
         if spec.norm == "normalize_adj":
@@ -276,7 +281,7 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
                   if windows else "k_spmm_rows (+ k_spmm_hub, same C-ABI call)")
     else:
         g = ddist.build_partitioned_graph(n_global, nnz_target, F, skew, spec.seed, spec.norm, world, rank, dev, ld,
-                                          comm_size=comm, mu=mu, exchange=args.exchange, K=K)
+                                          comm_size=comm, mu=mu, exchange=args.exchange, K=K, max_degree=max_deg)
         n_local, nnz, nnz_global = g.part.n_local, g.nnz_local, g.nnz_global
         order = args.order
         if order == "auto":
@@ -470,7 +475,7 @@ def main():
         watchdog.start()
     if run_extras:
         # (workload, generator, partition); partition None = --partition (auto: feature columns when the graph fits)
-        plan = [("products", "config", None), ("products", "community", None)]
+        plan = [("products", "config", None), ("products", "config-truncated", None), ("products", "community", None)]
         if world > 1:
             plan = [("reddit", "community", None)] + plan
             if world == 8 or args.extras == "all":
@@ -566,7 +571,7 @@ def compact_extra(e: dict) -> dict:
     if e.get("unit", "edges*feat/s") != "edges*feat/s":
         out["unit"] = e["unit"]
     if "graph" in c:
-        out["graph"] = c["graph"].split(",")[0][:28]
+        out["graph"] = c["graph"].split(",")[0][:28] + (" (head truncated)" if "truncated" in c["graph"] else "")
     if par and par != "single":
         out["partition"] = "features" if par.startswith("feature") else "rows"
     if c.get("row_order") == "locality":

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256, NV == 1 ? (TAIL ? 5 : 6) : 1) void k_spmm_rows
                                                        int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
                                                        const uint32_t* __restrict__ perm, int64_t first, int64_t count,
                                                        const uint32_t* __restrict__ wbeg, const uint32_t* __restrict__ wend,
-                                                       int first_window, int last_window, int flags, int rpg) {
+                                                       int first_window, int last_window, int flags, int rpg,
+                                                       int64_t slice_cp, int n_slices, int phase) {
   typedef typename Vec<VEC>::type V;
   constexpr int RPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -176,13 +177,38 @@ __global__ __launch_bounds__(256, NV == 1 ? (TAIL ? 5 : 6) : 1) void k_spmm_rows
   // table entries are fetched first, then the first (col, val) batch and the y block of row i+1 are in
   // flight while row i gathers -- the per-row chain table -> (col, y) -> gather overlaps across rows.
   constexpr int MAXR = 2;
-  const int64_t grp0 = (((int64_t)blockIdx.x * 4 + wave) * RPW + lane / G) * rpg;
+  int64_t chunk = blockIdx.x;
+  if (phase >= 0) {
+    // XCD-sliced skewed schedule (sweep_mode 5).  Workgroups are dealt to the 8 XCDs in turn, so the workgroups with
+    // blockIdx % 8 == j share an L2: in phase t they all gather from ONE window ("slice") s_j -- the one of
+    // {t-7 .. t} with s_j % 8 == j -- so the eight L2s hold eight DIFFERENT slices (8 x the distinct bytes of a launch
+    // in which every XCD caches the same window), and an XCD keeps its slice for 8 consecutive phases.  The row
+    // chunks are dealt into 8 groups (chunk % 8); group g meets slice s in phase s + g: every row visits the slices
+    // in ascending order (CSR order: same bits as the other kernels), one slice per phase, and in one phase the eight
+    // (group, slice) pairs are disjoint in rows, so y has one writer per row and launch.  Phases run as launches on
+    // one stream.  The block -> XCD deal is an observation, not a contract: it decides the speed only.
+    const int j = blockIdx.x & 7;
+    const int s = phase - ((phase - j) & 7);
+    if (s < 0 || s >= n_slices) return;
+    chunk = (int64_t)(blockIdx.x >> 3) * 8 + (phase - s);
+    wbeg += (int64_t)s * slice_cp;
+    wend = wbeg + slice_cp;
+    first_window = s == 0;
+    last_window = s == n_slices - 1;
+  }
+  const int64_t grp0 = ((chunk * 4 + wave) * RPW + lane / G) * rpg;
   if (grp0 >= count) return;
   int64_t rem_rows = count - grp0;
   const int nrow = rem_rows < rpg ? (int)rem_rows : rpg;
   int64_t off[NV];
   lane_offsets<VEC, G, NV>(nvec, gl, off);
+#if defined(DISCO_DBG_NORMW)
+  // timing experiment: the partial sums are neither read back nor stored (only a value that never occurs is): the
+  // kernel's speed without the read-modify-write of y
+  const bool resume = false;
+#else
   const bool resume = !first_window || (flags & FLAG_ACCUM);
+#endif
   // last window: the mean divides by the row length, the maximum of an empty row becomes 0
   const bool finalize = last_window && (OP == OP_MAX || (flags & FLAG_MEAN));
   uint32_t mb[MAXR], me[MAXR], mrow[MAXR];
@@ -240,6 +266,9 @@ __global__ __launch_bounds__(256, NV == 1 ? (TAIL ? 5 : 6) : 1) void k_spmm_rows
             V a = acc[v];
             if (cnt > 0.0f) a = vdiv<VEC>(a, cnt);
             if (empty_row) a = 0.0f;
+#if defined(DISCO_DBG_NORMW)
+            if constexpr (VEC == 4) { if (a[0] != 1.2345678e30f) continue; }
+#endif
             if constexpr (!TAIL && VEC == 4 && DISCO_WIN_YSTORE == 2) {
               typedef unsigned int u4 __attribute__((ext_vector_type(4)));
               const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, 0xffffffff, 0x27000);
@@ -682,15 +711,30 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       // the variant without a masked tail stores through a buffer descriptor on y (32-bit offsets, `sc1`): a y block of
       // 4 GiB or more takes the other variant, whose stores are plain and whose tail count may be 0
       const bool tail = (a.F % VEC) != 0 || (uint64_t)s.n_rows * (uint64_t)a.ldy * 4u >= (1ull << 32);
+      if (tuning().sweep_mode == 5 && P >= 2) {
+        // XCD-sliced skewed schedule: P + 7 phases, in each of them every XCD works on its own slice (kernel comment)
+        const int64_t blocks8 = (blocks + 7) / 8 * 8;
+        if (blocks8 > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
+        for (int t = 0; t < P + 7; ++t) {
+          if (tail)
+            hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, OP, HASVAL, A24, true>), dim3((unsigned)blocks8), dim3(256), 0, a.stream, a.rowptr, a.col,
+                               a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, wptr, wptr, 0, 0, mean | (((int)a.F & 3) << 8), rpg,
+                               s.sweep_count_padded, P, t);
+          else
+            hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, OP, HASVAL, A24, false>), dim3((unsigned)blocks8), dim3(256), 0, a.stream, a.rowptr, a.col,
+                               a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, wptr, wptr, 0, 0, mean, rpg,
+                               s.sweep_count_padded, P, t);
+        }
+      } else
       for (int w = 0; w < P; ++w) {
         if (tail)
           hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, OP, HASVAL, A24, true>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
                              a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, wptr + (int64_t)w * s.sweep_count_padded,
-                             wptr + (int64_t)(w + 1) * s.sweep_count_padded, w == 0, w == P - 1, mean | (((int)a.F & 3) << 8), rpg);
+                             wptr + (int64_t)(w + 1) * s.sweep_count_padded, w == 0, w == P - 1, mean | (((int)a.F & 3) << 8), rpg, (int64_t)0, 0, -1);
         else
           hipLaunchKernelGGL((k_spmm_rows_win<VEC, G, NV, OP, HASVAL, A24, false>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
                              a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, wptr + (int64_t)w * s.sweep_count_padded,
-                             wptr + (int64_t)(w + 1) * s.sweep_count_padded, w == 0, w == P - 1, mean, rpg);
+                             wptr + (int64_t)(w + 1) * s.sweep_count_padded, w == 0, w == P - 1, mean, rpg, (int64_t)0, 0, -1);
       }
       swept = true;
     }

@@ -122,6 +122,15 @@ __device__ __forceinline__ void lane_offsets(int nvec, int gl, int64_t (&off)[NV
 template <int VEC, bool A24>
 __device__ __forceinline__ typename Vec<VEC>::type gather_vec(const float* __restrict__ x, int64_t ldx, int c, int64_t off) {
   typedef typename Vec<VEC>::type V;
+  // Timing experiments only (tools/r3/exp_bounds.sh builds side libraries with these; results are then wrong by design):
+  //   DISCO_DBG_COLMASK=m   every gather goes to row (col & m): the kernel's speed if every gather hit the L2
+  //   DISCO_DBG_NOGATHER    no gather at all (the value is made from the column id): everything but the gathers
+#if defined(DISCO_DBG_COLMASK)
+  c &= DISCO_DBG_COLMASK;
+#endif
+#if defined(DISCO_DBG_NOGATHER)
+  { V r; r = (float)c * 1e-9f + (float)off; return r; }
+#endif
 #if defined(DISCO_GATHER_NT)
   // experiment: every gather carries `nt` (does the hint change what the L2 retains?  profiles/r2/gather_nt.log)
   if constexpr (A24) {

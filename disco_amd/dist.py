@@ -288,7 +288,7 @@ class PartitionedGraph:
 
 def build_partitioned_graph(n_global: int, nnz_global: int, F: int, skew: float, seed: int, norm: str, world: int, rank: int,
                             device, ld: int, comm_size: int = 0, mu: float = 1.0, exchange: str = "auto", K: int = 2,
-                            group=None, spmm_fn: Optional[Callable] = None) -> PartitionedGraph:
+                            group=None, spmm_fn: Optional[Callable] = None, max_degree: int = 0) -> PartitionedGraph:
     """Rank ``rank``'s row block of a GLOBAL symmetric graph (``graphgen.partition_edges``: every rank generates
     exactly the entries of its own rows, drawn over the global id range), normalised the way the reference
     normalises that dataset, wrapped in a ``RowPartition``.  How many halo rows / entries result is an OUTCOME
@@ -300,7 +300,7 @@ def build_partitioned_graph(n_global: int, nnz_global: int, F: int, skew: float,
     N-vector at set-up."""
     from . import graphgen
     row, col, offs = graphgen.partition_edges(n_global, nnz_global, skew, seed, world, rank, device, comm_size, mu,
-                                              add_diag=(norm == "normalize_adj"))
+                                              add_diag=(norm == "normalize_adj"), max_degree=max_degree)
     lo, hi = offs[rank], offs[rank + 1]
     n_local = hi - lo
     counts = torch.bincount(row, minlength=n_local)

@@ -300,6 +300,51 @@ def test_sweep_kernel_same_bits_as_plain(F, reduce, mode):
     _lib.load().disco_set_tuning(b"sweep_mode", 2)
 
 
+@pytest.mark.parametrize("F,wrows", [(128, 300), (128, 1500), (602, 97), (100, 640), (30, 4000)])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max", "sum_acc"])
+def test_xcd_sliced_schedule_same_bits_as_windowed_launches(F, wrows, reduce):
+    """sweep_mode 5 (XCD-sliced skewed schedule: in phase t the workgroups with blockIdx % 8 == j work on slice s_j and
+    row group t - s_j): every row still visits the slices in ascending order, one per phase, so the bits are those
+    of the windowed launches (mode 2) and, below the hub threshold, of the plain kernel -- with many slices, fewer
+    slices than XCDs, empty rows, a masked tail column block and y += A x."""
+    from disco_amd import _lib, ops
+    lib = _lib.load()
+    n = 5000
+    rowptr, col, val = random_csr(n, n, 60, seed=77, hubs=[(0, 4800), (9, 2100)], weighted=True)
+    x = np.random.default_rng(8).standard_normal((n, F)).astype(np.float32)
+    ld = (F + 31) // 32 * 32
+    xb = torch.zeros((n, ld), device=dev())
+    xb[:, :F] = torch.from_numpy(x).to(dev())
+    y0 = torch.from_numpy(np.random.default_rng(5).standard_normal((n, F)).astype(np.float32)).to(dev())
+
+    def run(mode):
+        adj = to_adj(rowptr, col, val, n)
+        _, info = adj.schedule(8192, 4096, feat=F, sweep=True, window_bytes=wrows * 4 * min(128, (F + 31) // 32 * 32))
+        assert info.sweep_ws and info.n_hub_rows == 0
+        lib.disco_set_tuning(b"sweep_mode", mode)
+        try:
+            out = torch.full((n, ld), 7.0, device=dev())
+            out[:, :F] = y0 if reduce == "sum_acc" else 0.0
+            ops.spmm_raw(adj, xb[:, :F], reduce, out=out[:, :F])
+            torch.cuda.synchronize()
+        finally:
+            lib.disco_set_tuning(b"sweep_mode", 2)
+        return out, int(info.sweep_windows)
+
+    y2, windows = run(2)
+    y5, _ = run(5)
+    assert windows == (n + wrows - 1) // wrows
+    assert torch.equal(y2, y5)
+    assert bool((y5[:, F:] == 7.0).all())
+    plain = to_adj(rowptr, col, val, n)
+    plain.schedule(8192, 4096, feat=F, sweep=False)
+    out = torch.full((n, ld), 7.0, device=dev())
+    out[:, :F] = y0 if reduce == "sum_acc" else 0.0
+    ops.spmm_raw(plain, xb[:, :F], reduce, out=out[:, :F])
+    if reduce != "sum_acc":      # per output element the same fma chain in CSR order, whatever the lane-group shape
+        assert torch.equal(out, y5)  # (y += A x: the plain kernel adds y0 last, the windowed ones start from it)
+
+
 def test_sweep_refuses_unsorted_columns():
     from disco_amd import ops
     rowptr, col, val = random_csr(300, 300, 20, seed=3, weighted=True, sort_cols=False)
