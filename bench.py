@@ -336,15 +336,17 @@ def run_spmm(ctx: Ctx, name: str, graph: str, steps: int, warmup: int, want_cpu:
     # HBM / fabric bytes per hop from the PMC passes committed under profiles/ for exactly this configuration
     # (bench.py cannot read hardware counters itself); null when no matching measurement exists.
     if world == 1 and gworld == 1 and args.scale == 1.0 and not args.feat:
-        try:
-            with open(os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            key = f"{name}_{graph}_{cfg['row_order']}_windows{cfg['l2_windows']}"
-            if key in pmc:
-                res["roofline"]["traffic"] = round(pmc[key]["traffic_bytes_per_hop"])
-                res["roofline"]["traffic_source"] = f"profiles/r2/pmc_traffic.json[{key}]"
-        except (OSError, KeyError, ValueError):
-            pass
+        key = f"{name}_{graph}_{cfg['row_order']}_windows{cfg['l2_windows']}"
+        for rnd in ("r3", "r2"):             # newest committed measurement of exactly this configuration
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as fh:
+                    pmc = json.load(fh)
+                if key in pmc:
+                    res["roofline"]["traffic"] = round(pmc[key]["traffic_bytes_per_hop"])
+                    res["roofline"]["traffic_source"] = f"profiles/{rnd}/pmc_traffic.json[{key}] (committed PMC passes, not this run)"
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
     if want_cpu and world == 1 and gworld == 1:
         res["cpu_baseline"] = cpu_baselines(adj, x, F, args)
     return res

@@ -226,6 +226,46 @@ def normalize_adj_tensor(adj: torch.Tensor, sparse: bool = False):
     return (r.unsqueeze(1) * a_hat) * r.unsqueeze(0)
 
 
+def normalize_sparse_tensor(adj: torch.Tensor, fill_value=1):
+    """/root/reference/utils.py:437-455 (the variant the reference keeps one comment away from use, :481): n self-loops
+    of weight ``fill_value`` are APPENDED (existing loops stay), ``deg = scatter_add(w, row)`` -- ROW degree, summed in
+    edge order in float32 like the serial CPU scatter_add --, ``deg^-1/2`` with inf -> 0, and
+    ``(deg_inv_sqrt[row] * w) * deg_inv_sqrt[col]`` left to right.  Returns an (uncoalesced) torch sparse COO tensor like
+    the reference.  Same kernels as ``gcn_norm`` (degree by row = ``flow="target_to_source"``)."""
+    _require_cuda(adj, "normalize_sparse_tensor")
+    edge_index, edge_weight = add_self_loops(adj._indices(), adj._values(), fill_value, adj.size(0))
+    edge_index, values = gcn_norm(edge_index, edge_weight, adj.size(0), add_self_loops=False, flow="target_to_source")
+    return torch.sparse_coo_tensor(edge_index, values, adj.shape)
+
+
+def sparse_mx_to_torch_sparse_tensor(sparse_mx) -> torch.Tensor:
+    """/root/reference/utils.py:632-639: scipy sparse matrix -> torch sparse COO float32 tensor (entries in the COO
+    order scipy hands back, values rounded to float32 once, int64 indices)."""
+    coo = sparse_mx.tocoo().astype("float32")
+    idx = torch.stack([torch.from_numpy(coo.row.astype("int64")), torch.from_numpy(coo.col.astype("int64"))])
+    return torch.sparse_coo_tensor(idx, torch.from_numpy(coo.data), torch.Size(coo.shape))
+
+
+def to_scipy(tensor: torch.Tensor):
+    """/root/reference/utils.py:651-660: dense or sparse torch tensor -> scipy CSR on the host (duplicate COO entries
+    are summed by ``csr_matrix``)."""
+    import scipy.sparse as sp
+    if is_sparse_tensor(tensor):
+        idx, val = tensor._indices(), tensor._values()
+    else:
+        idx = tensor.nonzero().t()
+        val = tensor[idx[0], idx[1]]
+    return sp.csr_matrix((val.cpu().numpy(), idx.cpu().numpy()), shape=tuple(tensor.shape))
+
+
+def to_tensor(adj, device="cpu") -> torch.Tensor:
+    """/root/reference/utils.py:322-341: adjacency as a torch tensor on ``device`` -- scipy sparse -> sparse COO float32,
+    anything else -> dense float32 (what ``LargeScaleCondensing.py:378`` feeds ``normalize_adj_tensor``)."""
+    import scipy.sparse as sp
+    out = sparse_mx_to_torch_sparse_tensor(adj) if sp.issparse(adj) else torch.as_tensor(adj, dtype=torch.float32)
+    return out.to(device)
+
+
 def to_undirected(edge_index: torch.Tensor, edge_attr=None, num_nodes: Optional[int] = None) -> torch.Tensor:
     """PyG ``to_undirected(edge_index, edge_attr=None, num_nodes=)`` as the reference calls it
     (/root/reference/utils.py:100): both directions of every edge, duplicates removed, sorted by

@@ -292,6 +292,22 @@ def spmm_abs_bound(rowptr, col, val, x):
     return spmm_csr(rowptr, col, v, np.abs(np.asarray(x, dtype=np.float64)), "sum", np.float64)
 
 
+def normalize_sparse_tensor(row, col, w, n, fill_value=1.0):
+    """/root/reference/utils.py:437-455: append n self-loops of ``fill_value``, ``deg = scatter_add(w, row)``
+    serially in float32 in edge order, ``deg^-1/2`` (inf -> 0, 1/sqrt correctly rounded), left-to-right float32
+    product.  Returns (row, col, values) with the loops appended."""
+    row = np.concatenate([np.asarray(row, np.int64), np.arange(n, dtype=np.int64)])
+    col = np.concatenate([np.asarray(col, np.int64), np.arange(n, dtype=np.int64)])
+    w = np.concatenate([np.asarray(w, np.float32), np.full(n, fill_value, np.float32)])
+    deg = np.zeros(n, np.float32)
+    for e in range(len(w)):                       # serial scatter_add, edge order
+        deg[row[e]] = np.float32(deg[row[e]] + w[e])
+    with np.errstate(divide="ignore"):
+        dis = (np.float32(1.0) / np.sqrt(deg, dtype=np.float32)).astype(np.float32)
+    dis[np.isinf(dis)] = 0
+    return row, col, ((dis[row] * w).astype(np.float32) * dis[col]).astype(np.float32)
+
+
 # --------------------------------------------------------------------------
 # A7: max aggregation of the edge-translation link predictor
 # --------------------------------------------------------------------------

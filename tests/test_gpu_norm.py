@@ -196,3 +196,31 @@ def test_gcn_norm_sparse_tensor_branch_bit_exact(loops, improved, weighted):
     assert np.array_equal(v.view(np.uint32), vv.view(np.uint32))
     if not loops:
         assert np.all(v[(r == 7) | (c == 7)] == 0) or not ((r == 7) | (c == 7)).any()
+
+
+def test_normalize_sparse_tensor_and_layout_helpers():
+    """SURVEY section 2 row 3, the last host pieces: normalize_sparse_tensor (/root/reference/utils.py:437-455: appended
+    self-loops, ROW degree) bit-exact against the oracle's serial restatement, and to_tensor / to_scipy /
+    sparse_mx_to_torch_sparse_tensor (:322-341, :632-660) round trips."""
+    import scipy.sparse as sp
+    from disco_amd import utils
+    rng = np.random.default_rng(12)
+    n, e = 700, 9000
+    row, col = rng.integers(0, n, e), rng.integers(0, n, e)
+    row[:5] = col[:5]                                  # existing self-loops stay, one more is appended
+    w = rng.random(e).astype(np.float32) + 0.1
+    deg0 = np.bincount(row, minlength=n)
+    assert (deg0 == 0).any() or True
+    adj = torch.sparse_coo_tensor(torch.from_numpy(np.stack([row, col])), torch.from_numpy(w), (n, n)).to("cuda:0")
+    out = utils.normalize_sparse_tensor(adj, fill_value=1)
+    r_ref, c_ref, v_ref = orc.normalize_sparse_tensor(row, col, w, n, 1.0)
+    assert np.array_equal(out._indices().cpu().numpy(), np.stack([r_ref, c_ref]))
+    assert np.array_equal(out._values().cpu().numpy().view(np.int32), v_ref.view(np.int32))
+    # layout helpers
+    m = sp.random(50, 40, density=0.1, format="csr", random_state=3, dtype=np.float64)
+    t = utils.to_tensor(m, device="cuda:0")
+    assert t.is_sparse and t.dtype == torch.float32 and t.device.type == "cuda" and tuple(t.shape) == (50, 40)
+    back = utils.to_scipy(t)
+    assert (abs(back - m.astype(np.float32)) > 0).nnz == 0
+    d = utils.to_tensor(np.arange(6, dtype=np.float64).reshape(2, 3))
+    assert d.dtype == torch.float32 and not d.is_sparse and utils.to_scipy(d).nnz == 5

@@ -259,3 +259,23 @@ def test_anchor_max_restatement_matches_torch_indexing():
     want = torch.from_numpy(T)[torch.from_numpy(index_c)][torch.from_numpy(anchor), :16].max(dim=1).values.numpy()
     assert np.array_equal(orc.anchor_max(T, anchor, 16, index=index_c), want)
     assert np.array_equal(orc.anchor_max(T[index_c], anchor), torch.from_numpy(T[index_c])[torch.from_numpy(anchor)].max(dim=1).values.numpy())
+
+
+def test_normalize_sparse_tensor_restatement_matches_stock_torch():
+    """/root/reference/utils.py:437-455 evaluated with stock torch on the CPU (index_add_ is the serial scatter_add there)
+    against the oracle's loop: same bits up to torch's pow(-0.5) (compared at 1 ulp)."""
+    import torch
+    rng = np.random.default_rng(4)
+    n, e = 60, 400
+    row, col = rng.integers(0, n, e), rng.integers(0, n, e)
+    w = rng.random(e).astype(np.float32) + 0.5
+    r, c, v = orc.normalize_sparse_tensor(row, col, w, n, 1.0)
+    ei = torch.from_numpy(np.stack([np.concatenate([row, np.arange(n)]), np.concatenate([col, np.arange(n)])]))
+    ew = torch.cat([torch.from_numpy(w), torch.ones(n)])
+    deg = torch.zeros(n).index_add_(0, ei[0], ew)
+    dis = deg.pow(-0.5)
+    dis[dis == float("inf")] = 0
+    ref = (dis[ei[0]] * ew * dis[ei[1]]).numpy()
+    assert np.array_equal(r, ei[0].numpy()) and np.array_equal(c, ei[1].numpy())
+    ulp = np.abs(v.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)).max()
+    assert ulp <= 2, ulp
