@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ r
 // that variant runs at 5 instead of 6 waves per SIMD rather than spilling).  !TAIL: write-through (`sc1`) stores of
 // the partial sums through a buffer descriptor on y (DISCO_WIN_YSTORE in disco_spmm_common.h; y block < 4 GiB).
 template <int VEC, int G, int NV, int OP, bool HASVAL, bool A24, bool TAIL>
-__global__ __launch_bounds__(256, NV == 1 ? (TAIL ? 5 : 6) : 1) void k_spmm_rows_win(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+__global__ __launch_bounds__(256, NV == 1 ? (TAIL ? DISCO_WIN_WAVES - 1 : DISCO_WIN_WAVES) : 1) void k_spmm_rows_win(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                        const float* __restrict__ val, const float* __restrict__ x,
                                                        int64_t ldx, float* __restrict__ y, int64_t ldy, int nvec,
                                                        const uint32_t* __restrict__ perm, int64_t first, int64_t count,
@@ -236,15 +236,35 @@ __global__ __launch_bounds__(256, NV == 1 ? (TAIL ? 5 : 6) : 1) void k_spmm_rows
       }
     }
   };
+#if DISCO_WIN_HOIST
+  // every row's first (col, val) batch and y block are requested BEFORE the first gather: vector-memory loads return
+  // in issue order, so a fabric-latency load issued between two rows' gathers would hold back the L2-hit gathers behind it
+  int cv_h[MAXR]; float wv_h[MAXR]; V y_h[MAXR][NV];
+#pragma unroll
+  for (int i = 0; i < MAXR; ++i) {
+    cv_h[i] = 0; wv_h[i] = 0.0f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) vinit<VEC, OP>(y_h[i][v]);
+    if (i < nrow) fetch(mb[i], me[i], mrow[i], cv_h[i], wv_h[i], y_h[i]);
+  }
+#else
   fetch(mb[0], me[0], mrow[0], cv_n, wv_n, y_n);
+#endif
 #pragma unroll
   for (int i = 0; i < MAXR; ++i) {
     if (i < nrow) {
+#if DISCO_WIN_HOIST
+      int cv = cv_h[i]; float wv = wv_h[i];
+      V acc[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] = y_h[i][v];
+#else
       int cv = cv_n; float wv = wv_n;
       V acc[NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) acc[v] = y_n[v];
       if (i + 1 < MAXR && i + 1 < nrow) fetch(mb[i + 1], me[i + 1], mrow[i + 1], cv_n, wv_n, y_n);
+#endif
       int64_t beg = mb[i], end = me[i], row = mrow[i];
       if constexpr (G == 64) { beg = uniform64(beg); end = uniform64(end); row = uniform64(row); }
       // nothing to add and nothing to finalise: leave the row alone

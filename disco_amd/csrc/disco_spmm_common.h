@@ -41,6 +41,15 @@ template <> struct Vec<4> { typedef f4 type; };
 #ifndef DISCO_WIN_YSTORE
 #define DISCO_WIN_YSTORE 2
 #endif
+// waves per SIMD the windowed kernel is compiled for (register budget 512 / waves; with DISCO_U1 gathers of 4 registers
+// in flight per lane): 6 waves x 8 gathers measured best (profiles/r3/exp_unroll_occupancy.log)
+#ifndef DISCO_WIN_WAVES
+#define DISCO_WIN_WAVES 6
+#endif
+// 1: the windowed kernel requests the (col, val) batch and the y block of ALL its rows before the first gather
+#ifndef DISCO_WIN_HOIST
+#define DISCO_WIN_HOIST 0
+#endif
 #ifndef DISCO_CSR_NT
 #define DISCO_CSR_NT 0
 #endif
