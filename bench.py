@@ -493,7 +493,9 @@ def main():
             if world == 8 or args.extras == "all":
                 plan += [("papers100M", "community", "rows"), ("papers100M", "config", "rows")]
         else:
-            plan += [("scorer", "", None)]
+            # N = 1: the pair scorer (configs[3]) and, last, the FULL papers100M-shaped graph on this one GPU (configs[4]'s
+            # single-GPU anchor: 111 M nodes, 1.6 G entries, ~185 GB resident)
+            plan += [("scorer", "", None), ("papers100M", "config", None)]
         for name, graph, part in plan:
             go = 1 if time.time() - t_start < args.extras_budget_s else 0
             if world > 1:       # rank 0 decides for everybody
