@@ -13,7 +13,7 @@ struct Tuning {
   int force_g = 0;    // 0 = automatic
   int force_nv = 0;   // 0 = automatic
   int max_vec = 0;    // 0 = 4
-  int sweep_mode = 2; // with a window table attached: 0 = ignore it, 1 = persistent sweep, 2 = windowed launches, 3 = paced persistent windows, 4 = streaming persistent windows
+  int sweep_mode = 2; // with a window table attached: 0 = ignore it, 1 = persistent sweep, 2 = windowed launches, 3 = paced persistent windows, 4 = streaming persistent windows, 5 = XCD-sliced skewed schedule of the windowed launches
   int win_cols = 0;   // column block width of the windowed launches (0 = 128)
   int win_rows_per_group = 0;  // consecutive rows one lane group handles per windowed launch (0 = 2, at most 2)
   int sweep_blocks_per_cu = 0;  // 0 = 4

@@ -274,7 +274,8 @@ int disco_sym_threshold_fill(const float* S, int64_t n, int64_t lds, float thres
 
 /* Benchmark / test knobs: "force_g", "force_nv", "max_vec" (lane-group shape), "sweep_mode" (with a window table
  * attached: 0 ignore it, 1 persistent sweep, 2 windowed launches [default], 3 paced persistent windows, 4 streaming
- * persistent windows [experimental, DESIGN.md 3.4]), "stream_u" (mode 4: gathers in flight per wave), "xcd_map"
+ * persistent windows [experimental, DESIGN.md 3.4], 5 XCD-sliced skewed schedule of the windowed launches [same bits as 2;
+ * measured slower, DESIGN.md 3.4b]), "stream_u" (mode 4: gathers in flight per wave), "xcd_map"
  * (k_spmm_rows: -1 [default] = info->xcd_run decides, 0 = off, 1 = one contiguous eighth of the row order per XCD,
  * S > 1 = runs of S rows), "row_cols" (column block of the plain row kernel: 0 = 128 floats under a group-major
  * schedule and one pass otherwise, -1 = never block, > 0 = that width), "narrow_groups" (0 = no 4- / 8-lane row groups),
