@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, NV == 1 ? (TAIL ? DISCO_WIN_WAVES - 1 : DISCO_
   // A group handles up to MAXR consecutive rows (positions) per launch, software-pipelined: all their
   // table entries are fetched first, then the first (col, val) batch and the y block of row i+1 are in
   // flight while row i gathers -- the per-row chain table -> (col, y) -> gather overlaps across rows.
-  constexpr int MAXR = 2;
+  constexpr int MAXR = DISCO_WIN_MAXR;
   int64_t chunk = blockIdx.x;
   if (phase >= 0) {
     // XCD-sliced skewed schedule (sweep_mode 5).  Workgroups are dealt to the 8 XCDs in turn, so the workgroups with
@@ -724,8 +724,8 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       const disco_schedule_info& s = *a.info;
       const uint32_t* wptr = reinterpret_cast<const uint32_t*>(s.sweep_ws);
       const int P = (int)s.sweep_windows;
-      int rpg = tuning().win_rows_per_group > 0 ? tuning().win_rows_per_group : 2;
-      if (rpg > 2) rpg = 2;
+      int rpg = tuning().win_rows_per_group > 0 ? tuning().win_rows_per_group : DISCO_WIN_MAXR;
+      if (rpg > DISCO_WIN_MAXR) rpg = DISCO_WIN_MAXR;
       int64_t blocks = (count + 4 * RPW * rpg - 1) / (4 * RPW * rpg);
       if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
       // the variant without a masked tail stores through a buffer descriptor on y (32-bit offsets, `sc1`): a y block of

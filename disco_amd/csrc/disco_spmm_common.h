@@ -50,6 +50,10 @@ template <> struct Vec<4> { typedef f4 type; };
 #ifndef DISCO_WIN_HOIST
 #define DISCO_WIN_HOIST 0
 #endif
+// consecutive rows one lane group of the windowed kernel handles per launch (software-pipelined one row ahead)
+#ifndef DISCO_WIN_MAXR
+#define DISCO_WIN_MAXR 2
+#endif
 #ifndef DISCO_CSR_NT
 #define DISCO_CSR_NT 0
 #endif
