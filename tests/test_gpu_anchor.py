@@ -93,3 +93,23 @@ def test_anchor_max_through_the_raw_c_abi_leaves_other_rows_alone():
     assert lib.disco_anchor_max_f32(t.data_ptr(), 300, 64, 96, None, 0, a.data_ptr(), 40, 3, None, 80, out.data_ptr(), 160, None, None) == -1
     assert lib.disco_anchor_max_f32(t.data_ptr(), 300, 128, 96, None, 0, a.data_ptr(), 40, 0, None, 80, out.data_ptr(), 160, None, None) == -1
     assert lib.disco_anchor_max_f32(t.data_ptr(), 300, 128, 96, None, 0, a.data_ptr(), 40, 3, None, 10, out.data_ptr(), 160, None, None) == -1
+
+
+def test_anchor_max_empty_and_misaligned_operands():
+    """Edge cases: no synthetic node in a class, zero width, a feature table whose rows are not 16-byte aligned (copied
+    once into a padded buffer by the host side) and an output that is a column view of a wider matrix."""
+    from disco_amd import ops
+    T, anchor = _case(40, 7, 9, 3, seed=2)
+    t = torch.from_numpy(T).to(DEV)
+    a = torch.from_numpy(anchor).to(DEV)
+    assert ops.anchor_max(t, a[:0]).shape == (0, 7)
+    assert ops.anchor_max(t, a, 0).shape == (9, 0)
+    got = ops.anchor_max(t, a, 5)                                   # pitch of 7 floats: scalar path or padded copy
+    assert np.array_equal(got.cpu().numpy(), orc.anchor_max(T, anchor, 5))
+    wide = torch.full((9, 23), -2.0, device=DEV)
+    ops.anchor_max(t, a, 6, out=wide[:, 11:17])                     # unaligned column view of a wider output
+    w = wide.cpu().numpy()
+    assert np.array_equal(w[:, 11:17], orc.anchor_max(T, anchor, 6))
+    assert (w[:, :11] == -2.0).all() and (w[:, 17:] == -2.0).all()
+    with pytest.raises(ValueError):
+        ops.anchor_max(t, a, 8)                                     # wider than the table
