@@ -45,7 +45,14 @@ def add_remaining_self_loops(edge_index, edge_weight, fill_value, num_nodes):
     mask = row != col
     loop_w = edge_weight.new_full((num_nodes,), fill_value)
     inv = ~mask
-    loop_w[row[inv]] = edge_weight[inv]
+    # several loops on one node: the LAST one in edge order wins, as the serial CPU assignment of the reference's stack
+    # does -- an indexed assignment with repeated indices has no defined winner on the device, so pick it explicitly
+    pos = torch.nonzero(inv).flatten()
+    if pos.numel():
+        last = torch.full((num_nodes,), -1, dtype=torch.long, device=edge_index.device)
+        last.scatter_reduce_(0, row[pos], pos, reduce="amax", include_self=True)
+        has = last >= 0
+        loop_w[has] = edge_weight[last[has]]
     loops = torch.arange(num_nodes, dtype=edge_index.dtype, device=edge_index.device)
     ei = torch.cat([edge_index[:, mask], torch.stack([loops, loops])], dim=1)
     ew = torch.cat([edge_weight[mask], loop_w])
@@ -120,6 +127,9 @@ def gcn_norm(edge_index: Union[torch.Tensor, SparseTensor], edge_weight: Optiona
             else:
                 _lib.check(lib.disco_degree_count_f32(_lib.ptr(idx), E, num_nodes, _lib.ptr(deg), s), "disco_degree_count_f32")
             w = None
+        elif E == 0:
+            w = edge_weight.to(torch.float32).contiguous()
+            deg.zero_()
         else:
             w = edge_weight.to(torch.float32).contiguous()
             order = torch.argsort(idx, stable=True)

@@ -95,3 +95,90 @@ def test_random_case_against_oracle(case):
         plain = run(False)[:, :F]
         keep = np.diff(rowptr) <= 2048
         assert np.array_equal(y[keep], plain[keep]), f"{c}: windowed bits differ from the plain kernel below the hub threshold"
+
+
+@pytest.mark.parametrize("case", list(range(24)))
+def test_random_gcn_norm_bit_exact(case):
+    """A1 (/root/reference/utils.py:228-247) over random edge lists: weighted or not, either flow, with and without the
+    remaining self-loops, isolated nodes, duplicate edges, existing loops -- weights bit for bit against the oracle."""
+    from disco_amd import utils
+    from helpers import orc
+    rng = np.random.default_rng(500 + case)
+    n = int(rng.choice([1, 6, 200, 3000]))
+    E = int(rng.choice([0, 1, 5 * n, 40 * n]))
+    ei = rng.integers(0, n, (2, E))
+    if E > 4:
+        ei[:, :2] = ei[:, 2:4]                                  # duplicate edges
+        ei[1, 4 % E] = ei[0, 4 % E]                             # an existing self-loop
+    if n > 10:
+        ei[ei == 3] = 4                                         # node 3 isolated
+    weighted = bool(rng.random() < 0.6)
+    loops = bool(rng.random() < 0.5)
+    flow = "source_to_target" if loops or rng.random() < 0.5 else "target_to_source"
+    w = (rng.random(E).astype(np.float32) + 0.05) if weighted else None
+    ei_ref, ref = orc.gcn_norm_coo(ei, w, n, add_self_loops=loops, flow=flow)
+    ei_got, got = utils.gcn_norm(torch.from_numpy(ei).to(DEV), None if w is None else torch.from_numpy(w).to(DEV), n,
+                                 add_self_loops=loops, flow=flow)
+    assert np.array_equal(ei_got.cpu().numpy(), ei_ref)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), np.asarray(ref, np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("case", list(range(24)))
+def test_random_khop_against_oracle(case):
+    """A4: K = 1..3 hops through disco_khop_csr_f32 (ping-pong buffers, optional column slices) on random square graphs
+    with hub rows, against the float64 oracle."""
+    from disco_amd import SparseTensor, ops
+    from helpers import orc
+    rng = np.random.default_rng(700 + case)
+    n = int(rng.choice([3, 150, 1200]))
+    F = int(rng.choice([1, 5, 64, 100, 128, 200]))
+    K = int(rng.integers(1, 4))
+    slices = int(rng.choice([1, 1, 2, 3]))
+    hubs = [(int(rng.integers(0, n)), 3000)] if n >= 150 and rng.random() < 0.5 else []
+    rowptr, col, val = random_csr(n, n, float(rng.choice([2, 20])), seed=700 + case, hubs=hubs, weighted=True)
+    val = (val * np.float32(0.2)).astype(np.float32)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    adj = SparseTensor(rowptr=torch.from_numpy(rowptr).to(DEV), col=torch.from_numpy(col).to(DEV),
+                       value=torch.from_numpy(val).to(DEV), sparse_sizes=(n, n), is_sorted=True)
+    y = ops.khop(adj, torch.from_numpy(x).to(DEV), K, n_col_slices=slices).cpu().numpy()
+    y64 = orc.khop_csr(rowptr, col, val, x, K, np.float64)
+    bound = np.abs(x).astype(np.float64)
+    for _ in range(K):
+        bound = orc.spmm_abs_bound(rowptr, col, val, bound)
+    assert_fwd_close(y, y64, K * bound, what=f"case {case}: n={n} F={F} K={K} slices={slices}")
+
+
+@pytest.mark.parametrize("case", list(range(16)))
+def test_random_normalize_adj_tensor_against_oracle(case):
+    """A3 (/root/reference/utils.py:473-484 -> :406-435) over random sparse COO tensors with duplicates, isolated nodes and
+    either state of the mx[0, 0] rule: structure identical, values within 1 float32 ulp of the oracle's scipy restatement
+    in the float64 mode (identity added) and 4 ulp in the float32 mode (numpy's float32 power is a few ulp off)."""
+    from disco_amd import utils
+    from helpers import orc
+    rng = np.random.default_rng(900 + case)
+    n = int(rng.choice([2, 9, 400, 2500]))
+    E = min(int(rng.choice([n, 6 * n, 30 * n])), n * n)
+    cells = rng.choice(n * n, E, replace=False)                # distinct cells ...
+    row, col = cells // n, cells % n
+    if E > 6:                                                  # ... plus three entries given twice: csr_matrix sums them (a sum
+        row, col = np.concatenate([row, row[:3]]), np.concatenate([col, col[:3]])     # of two is order independent; scipy
+    # sorts a row's entries with an unstable sort before folding, so the float32 sum of three or more has no defined order)
+    loop0 = bool(case % 2)
+    if loop0:
+        row[-1], col[-1] = 0, 0                                # node 0 has a self-loop: no identity, float32 mode
+    else:
+        keep = ~((row == 0) & (col == 0))
+        row, col = row[keep], col[keep]
+    if n > 20:
+        row[row == 5] = 6                                      # row 5 empty: rowsum 0 -> r = 0 (float32 mode) or 1 (identity)
+    val = (rng.random(len(row)).astype(np.float32) + 0.1)
+    adj = torch.sparse_coo_tensor(torch.from_numpy(np.stack([row, col])), torch.from_numpy(val), (n, n)).to(DEV)
+    out = utils.normalize_adj_tensor(adj, sparse=True)
+    r_ref, c_ref, v_ref = orc.normalize_adj_scipy(row, col, val, n)
+    idx, v = out.indices().cpu().numpy(), out.values().cpu().numpy()
+    keep = v != 0
+    order = np.lexsort((c_ref, r_ref))
+    nz = v_ref[order] != 0
+    assert np.array_equal(idx[0][keep], r_ref[order][nz]) and np.array_equal(idx[1][keep], c_ref[order][nz])
+    ulp = np.abs(v[keep].view(np.int32).astype(np.int64) - v_ref[order][nz].view(np.int32).astype(np.int64)).max()
+    assert ulp <= (4 if loop0 else 1), (case, int(ulp))
