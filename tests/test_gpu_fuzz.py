@@ -182,3 +182,122 @@ def test_random_normalize_adj_tensor_against_oracle(case):
     assert np.array_equal(idx[0][keep], r_ref[order][nz]) and np.array_equal(idx[1][keep], c_ref[order][nz])
     ulp = np.abs(v[keep].view(np.int32).astype(np.int64) - v_ref[order][nz].view(np.int32).astype(np.int64)).max()
     assert ulp <= (4 if loop0 else 1), (case, int(ulp))
+
+
+@pytest.mark.parametrize("case", list(range(12)))
+def test_random_scorer_against_module_and_oracle(case):
+    """A9 over random scorers: hidden width 32 / 64 / 128 / 256, odd node counts and feature widths, non-trivial BatchNorm
+    running statistics.  Logits of the HIP scorer against the module's plain torch layers over explicit [z_i || z_j] rows
+    (the reference's loop, LargeScaleCondensing.py:304-305); fused edge construction = dense path bit for bit; the dense
+    path = the oracle's post-processing of the same scores, for a random variant and threshold."""
+    from disco_amd.models.parametrized_adj_lp import PGE_Edge
+    from helpers import orc
+    rng = np.random.default_rng(300 + case)
+    torch.manual_seed(300 + case)
+    n = int(rng.choice([1, 2, 63, 65, 200, 333]))
+    nfeat = int(rng.choice([3, 16, 50, 128]))
+    H = int(rng.choice([32, 64, 128, 256]))
+    m = PGE_Edge(nfeat=nfeat, nhid=H).to(DEV)
+    with torch.no_grad():
+        for bn in m.bns:
+            bn.running_mean.normal_(0, 0.3)
+            bn.running_var.uniform_(0.3, 1.7)
+            bn.weight.normal_(1.0, 0.3)
+            bn.bias.normal_(0, 0.2)
+    m.eval()
+    Z = torch.randn(n, nfeat, device=DEV)
+    L = m.score_all_pairs(Z, logits=True)
+    with torch.no_grad():
+        pairs = torch.cat([Z[:, None, :].expand(n, n, nfeat), Z[None, :, :].expand(n, n, nfeat)], dim=2).reshape(n * n, 2 * nfeat)
+        ref = m.logits(pairs).reshape(n, n)
+    assert torch.allclose(L, ref, rtol=2e-5, atol=2e-5), float((L - ref).abs().max())
+    S = m.score_all_pairs(Z)
+    variant = str(rng.choice(["transductive", "inductive", "sampled"]))
+    thr = float(np.quantile(S.cpu().numpy(), float(rng.choice([0.2, 0.7, 0.97])))) if n > 2 else 0.5
+    ei_f, ew_f = m.edge_construction(Z, thr, variant)
+    ei_d, ew_d = m.edge_construction(Z, thr, variant, fused=False)
+    assert torch.equal(ei_f, ei_d) and torch.equal(ew_f, ew_d)
+    rei, rew = orc.edge_construction(S.cpu().numpy(), thr, variant)
+    assert np.array_equal(ei_d.cpu().numpy(), rei) and np.array_equal(ew_d.cpu().numpy(), rew)
+    small = m.edge_construction(Z, thr, variant, capacity=1)          # overflow of the edge buffer: one retry, same list
+    assert torch.equal(small[0], ei_f) and torch.equal(small[1], ew_f)
+
+
+@pytest.mark.parametrize("case", list(range(16)))
+def test_random_spmm_gradients_against_dense_autograd(case):
+    """F4: dX = A^T dY through ops.spmm's autograd (sum and mean), rectangular shapes, hub rows, against float64 dense
+    autograd of the same product."""
+    from disco_amd import SparseTensor, ops
+    rng = np.random.default_rng(400 + case)
+    n, m_ = int(rng.choice([1, 40, 700])), int(rng.choice([3, 90, 700]))
+    F = int(rng.choice([1, 7, 64, 100, 130]))
+    reduce = "mean" if case % 2 else "sum"
+    hubs = [(0, 1500)] if n >= 40 and rng.random() < 0.5 else []
+    rowptr, col, val = random_csr(n, m_, float(rng.choice([1, 12])), seed=400 + case, hubs=hubs, weighted=True, dup=bool(case % 3 == 0))
+    adj = SparseTensor(rowptr=torch.from_numpy(rowptr).to(DEV), col=torch.from_numpy(col).to(DEV),
+                       value=torch.from_numpy(val).to(DEV), sparse_sizes=(n, m_), is_sorted=True)
+    x = torch.randn(m_, F, device=DEV, requires_grad=True)
+    g = torch.randn(n, F, device=DEV)
+    y = ops.spmm(adj, x, reduce)
+    y.backward(g)
+    row = np.repeat(np.arange(n), np.diff(rowptr))
+    A = torch.zeros(n, m_, dtype=torch.float64, device=DEV).index_put_(
+        (torch.from_numpy(row).to(DEV), torch.from_numpy(col).to(DEV)), torch.from_numpy(val).double().to(DEV), accumulate=True)
+    Aabs = A.abs()
+    if reduce == "mean":
+        cnt = torch.from_numpy(np.maximum(np.diff(rowptr), 1)).double().to(DEV)[:, None]
+        A, Aabs = A / cnt, Aabs / cnt
+    xd = x.detach().double().requires_grad_(True)
+    yd = A @ xd
+    yd.backward(g.double())
+    by, bg = Aabs @ x.detach().abs().double(), Aabs.T @ g.abs().double()
+    assert bool(((y.detach().double() - yd.detach()).abs() <= 1e-5 * by + 1e-30).all())
+    assert bool(((x.grad.double() - xd.grad).abs() <= 1e-5 * bg + 1e-30).all())
+
+
+@pytest.mark.parametrize("case", list(range(16)))
+def test_random_coo_to_csr_and_transpose(case):
+    """F3 + the transposed structure backward uses: disco_coo_to_csr in its three duplicate modes (with and without
+    symmetrisation) against numpy / scipy on random rectangular edge lists, and SparseTensor.t() against scipy's transpose
+    (entries of a column in original row order, values carried along)."""
+    import scipy.sparse as sp
+    from disco_amd import SparseTensor
+    from disco_amd.sparse import coo_to_csr
+    rng = np.random.default_rng(600 + case)
+    n = int(rng.choice([1, 5, 300, 5000]))
+    sym = bool(case % 4 == 0)
+    m_ = n if sym else int(rng.choice([1, 7, 900]))
+    E = int(rng.choice([0, 1, 4 * n, 25 * n]))
+    r, c = rng.integers(0, n, E), rng.integers(0, m_, E)
+    if E > 8:
+        r[:4], c[:4] = r[4:8], c[4:8]
+    w = rng.integers(1, 5, E).astype(np.float32)              # small integers: float32 sums are exact in any order
+    dup = ["keep", "sum", "first"][case % 3]
+    rp, ci, v = coo_to_csr(torch.from_numpy(r).to(DEV), torch.from_numpy(c).to(DEV), torch.from_numpy(w).to(DEV), (n, m_),
+                           dup=dup, symmetrise=sym)
+    rr, cc, ww = (np.concatenate([r, c]), np.concatenate([c, r]), np.concatenate([w, w])) if sym else (r, c, w)
+    order = np.lexsort((np.arange(len(rr)), cc, rr))
+    rr, cc, ww = rr[order], cc[order], ww[order]
+    if dup != "keep" and len(rr):
+        key = rr * m_ + cc
+        first = np.concatenate([[True], key[1:] != key[:-1]])
+        grp = np.cumsum(first) - 1
+        ww = np.bincount(grp, weights=ww).astype(np.float32) if dup == "sum" else ww[first]
+        rr, cc = rr[first], cc[first]
+    ref_rp = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(rr, minlength=n), out=ref_rp[1:])
+    assert np.array_equal(rp.cpu().numpy(), ref_rp)
+    assert np.array_equal(ci.cpu().numpy().astype(np.int64), cc) and np.array_equal(v.cpu().numpy(), ww)
+    # transpose of the resulting CSR
+    adj = SparseTensor(rowptr=rp, col=ci, value=v, sparse_sizes=(n, m_), is_sorted=True)
+    t = adj.t()
+    trp, tci, tv = (a.cpu().numpy() for a in t.csr())
+    row_of = np.repeat(np.arange(n), np.diff(ref_rp))
+    o2 = np.lexsort((np.arange(len(cc)), row_of, cc))
+    ref_trp = np.zeros(m_ + 1, np.int64)
+    np.cumsum(np.bincount(cc, minlength=m_), out=ref_trp[1:])
+    assert t.sparse_sizes() == (m_, n) and np.array_equal(trp, ref_trp)
+    assert np.array_equal(tci, row_of[o2]) and np.array_equal(tv, ww[o2])
+    if len(cc):
+        dense = sp.csr_matrix((ww.astype(np.float64), cc, ref_rp), shape=(n, m_)).toarray()
+        assert np.array_equal(sp.csr_matrix((tv.astype(np.float64), tci, trp), shape=(m_, n)).toarray(), dense.T)
