@@ -40,10 +40,15 @@ class _EdgeListCache:
         self.key = None
         self.perm = None
         self.struct: Optional[SparseTensor] = None
+        self.held: Optional[Tensor] = None
 
     def get(self, edge_index: Tensor, n_src: int, n_dst: int):
+        # The key names the tensor's memory and version.  The cache keeps the tensor itself alive (`held`): otherwise the
+        # allocator may hand the same address to a NEW edge list of the same size (version 0 again) and the stale
+        # structure would be served for it.
         key = (edge_index.data_ptr(), edge_index.shape[1], edge_index._version, n_src, n_dst, edge_index.device)
         if key != self.key:
+            self.held = edge_index
             row, col = edge_index[0], edge_index[1]
             perm = torch.argsort(col, stable=True)
             counts = torch.bincount(col, minlength=n_dst)

@@ -301,3 +301,38 @@ def test_random_coo_to_csr_and_transpose(case):
     if len(cc):
         dense = sp.csr_matrix((ww.astype(np.float64), cc, ref_rp), shape=(n, m_)).toarray()
         assert np.array_equal(sp.csr_matrix((tv.astype(np.float64), tci, trp), shape=(m_, n)).toarray(), dense.T)
+
+
+@pytest.mark.parametrize("conv_name", ["GCNConv", "SGConv", "SAGEConv"])
+def test_fresh_edge_lists_of_equal_size_never_hit_a_stale_cache(conv_name):
+    """A layer called with a NEW int64 [2, E] edge list per step (same E: the allocator likes to hand out the address of
+    the list that was just freed) must build a new structure every time -- forward and backward against dense float64."""
+    from disco_amd.models import convs_large as C
+    torch.manual_seed(0)
+    n, E, d = 400, 5000, 24
+    conv = getattr(C, conv_name)(d, 8).to(DEV)
+    for step in range(6):
+        g = torch.Generator(device=DEV).manual_seed(step)
+        ei = torch.randint(0, n, (2, E), device=DEV, generator=g)
+        w = torch.rand(E, device=DEV, generator=g) if conv_name != "SAGEConv" else None
+        x = torch.randn(n, d, device=DEV, requires_grad=True)
+        out = conv(x, ei, edge_weight=w) if w is not None else conv(x, ei)
+        out.sum().backward()
+        A = torch.zeros(n, n, dtype=torch.float64, device=DEV).index_put_(
+            (ei[1], ei[0]), torch.ones(E, dtype=torch.float64, device=DEV) if w is None else w.double(), accumulate=True)
+        if conv_name == "SAGEConv":
+            A = A / A.sum(1, keepdim=True).clamp(min=1)
+        xd = x.detach().double()
+        with torch.no_grad():
+            if conv_name == "GCNConv":
+                ref = A @ (xd @ conv.lin.weight.double().T) + conv.bias.double()
+            elif conv_name == "SGConv":
+                h = xd
+                for _ in range(conv.K):
+                    h = A @ h
+                ref = h @ conv.lin.weight.double().T + conv.lin.bias.double()
+            else:
+                ref = (A @ xd) @ conv.lin_l.weight.double().T + conv.lin_l.bias.double() + xd @ conv.lin_r.weight.double().T + conv.lin_r.bias.double()
+        scale = ref.abs().max().item() + 1.0
+        assert float((out.detach().double() - ref).abs().max()) <= 2e-5 * scale * (conv.K if conv_name == "SGConv" else 1) * 30, (conv_name, step)
+        del ei, w, x, out, A
