@@ -420,7 +420,9 @@ class SparseTensor:
 
     def set_row_groups(self, groups: Optional[torch.Tensor]) -> None:
         """Process rows group by group (``disco_schedule_build_grouped``); None returns to the degree-binned order.
-        Results do not change by a bit: only the order in which rows are processed does."""
+        Rows below the hub threshold keep every bit: only the order in which rows are processed changes.  (Hub rows, too,
+        up to F = 160; wider tables are walked in 128-column blocks here, which changes the association of a hub piece's
+        sum -- 1 ulp)"""
         if groups is not None:
             assert groups.numel() == self._sizes[0] and groups.device == self.device
             groups = groups.to(torch.int32).contiguous()

@@ -336,3 +336,108 @@ def test_fresh_edge_lists_of_equal_size_never_hit_a_stale_cache(conv_name):
         scale = ref.abs().max().item() + 1.0
         assert float((out.detach().double() - ref).abs().max()) <= 2e-5 * scale * (conv.K if conv_name == "SGConv" else 1) * 30, (conv_name, step)
         del ei, w, x, out, A
+
+
+@pytest.mark.parametrize("case", list(range(16)))
+def test_random_row_groups_keep_every_bit(case):
+    """Row groups (random labels, the locality pass's labels, one giant group, one group per row) only reorder the rows a
+    launch walks: the result must carry the bits of the degree-binned order, for every reduce, with and without windows."""
+    from disco_amd import SparseTensor, ops
+    rng = np.random.default_rng(4000 + case)
+    n = int(rng.choice([3, 257, 1500, 6000]))
+    F = int(rng.choice([1, 16, 41, 128, 200]))
+    hubs = [(int(rng.integers(0, n)), 5000)] if n > 1000 and rng.random() < 0.5 else []
+    rowptr, col, val = random_csr(n, n, float(rng.choice([2, 25])), seed=4000 + case, hubs=hubs, weighted=True, dup=False)
+    reduce = str(rng.choice(["sum", "mean", "max"]))
+    x = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(DEV)
+    window = bool(rng.random() < 0.5)
+
+    def build():
+        a = SparseTensor(rowptr=torch.from_numpy(rowptr).to(DEV), col=torch.from_numpy(col).to(DEV),
+                         value=None if reduce == "max" else torch.from_numpy(val).to(DEV), sparse_sizes=(n, n), is_sorted=True)
+        return a
+
+    base = build()
+    base.schedule(2048, 1024, feat=F, sweep=window, window_bytes=64 * 4 * min(128, (F + 31) // 32 * 32))
+    ref = ops.spmm_raw(base, x, reduce)
+    kind = case % 4
+    g = build()
+    if kind == 0:
+        labels = torch.from_numpy(rng.integers(0, max(1, n // 50), n)).to(DEV)
+    elif kind == 1:
+        labels = g.locality_groups(sweeps=4, max_group=int(rng.choice([0, 64, 1000])))
+    elif kind == 2:
+        labels = torch.zeros(n, dtype=torch.int64, device=DEV)
+    else:
+        labels = torch.arange(n, device=DEV).flip(0)
+    g.set_row_groups(labels)
+    g.schedule(2048, 1024, feat=F, sweep=window, window_bytes=64 * 4 * min(128, (F + 31) // 32 * 32))
+    got = ops.spmm_raw(g, x, reduce)
+    # hub rows: the grouped order walks tables wider than 160 floats in 128-column blocks, which changes the number of lane
+    # groups that share a hub piece and with it the association of that piece's sum (max has no rounding)
+    keep = torch.from_numpy((np.diff(rowptr) <= 2048) | (F <= 160) | (reduce == "max")).to(DEV)
+    assert torch.equal(got[keep], ref[keep]), (case, kind, n, F, reduce, window)
+    if not bool(keep.all()):
+        y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x.cpu().numpy(), want_bound=True)
+        if reduce == "mean":
+            cnt = np.maximum(np.diff(rowptr), 1)[:, None].astype(np.float64)
+            y64, bound = y64 / cnt, bound / cnt
+        assert_fwd_close(got.cpu().numpy(), y64, bound, what=f"grouped order, hub rows {case}")
+    g.set_row_groups(None)
+    g.schedule(2048, 1024, feat=F, sweep=window, window_bytes=64 * 4 * min(128, (F + 31) // 32 * 32))
+    assert torch.equal(ops.spmm_raw(g, x, reduce), ref), "back to the degree-binned order"
+
+
+@pytest.mark.parametrize("case", list(range(16)))
+def test_random_pair_gather_is_torch_indexing(case):
+    """F3 (/root/reference/LargeScaleCondensing.py:190-191): concat(z[src[sel]], z[dst[sel]]) -- bit for bit against torch
+    indexing over random widths, strides, selections (repeats, empty, every edge) and int32 / int64 edge lists."""
+    from disco_amd import ops
+    rng = np.random.default_rng(5000 + case)
+    n = int(rng.choice([1, 9, 500, 20000]))
+    w = int(rng.choice([1, 3, 4, 32, 41, 128, 300]))
+    ld = w + int(rng.choice([0, 1, 3, 4]))
+    E = int(rng.choice([0, 1, 77, 30000]))
+    zb = torch.from_numpy(rng.standard_normal((n, ld)).astype(np.float32)).to(DEV)
+    z = zb[:, :w]
+    ei = torch.from_numpy(rng.integers(0, n, (2, E))).to(DEV)
+    if rng.random() < 0.3:
+        ei = ei.to(torch.int32)
+    mode = case % 3
+    sel = None if mode == 0 or E == 0 else torch.from_numpy(rng.integers(0, E, int(rng.choice([0, 1, 513, 4096])))).to(DEV)
+    got = ops.pair_gather(z, ei, sel)
+    s, d = ei[0].long(), ei[1].long()
+    if sel is not None:
+        s, d = s[sel], d[sel]
+    ref = torch.cat((z[s], z[d]), dim=1)
+    assert got.shape == ref.shape and torch.equal(got, ref), (case, n, w, ld, E, mode)
+    if E > 0:
+        bad = ei.clone()
+        bad[1, int(rng.integers(0, E))] = n
+        if sel is None or (sel.numel() and False):
+            with pytest.raises(IndexError):
+                ops.pair_gather(z, bad, None)
+
+
+@pytest.mark.parametrize("case", list(range(12)))
+def test_random_khop_column_slices_keep_every_bit(case):
+    """A4 with n_col_slices > 1 (each slice runs its K hops before the next starts) must carry the bits of the unsliced
+    call: the slices touch disjoint columns and the rows' sums do not depend on the slice."""
+    from disco_amd import SparseTensor, ops
+    rng = np.random.default_rng(6000 + case)
+    n = int(rng.choice([5, 400, 3000]))
+    F = int(rng.choice([4, 33, 128, 256, 300, 602]))
+    K = int(rng.choice([1, 2, 3, 5]))
+    rowptr, col, val = random_csr(n, n, float(rng.choice([1, 8, 40])), seed=6000 + case, hubs=[], weighted=True, dup=False)
+    val = (val / np.maximum(np.add.reduceat(np.abs(val), np.minimum(rowptr[:-1], max(len(val) - 1, 0))).repeat(np.diff(rowptr)), 1e-3)
+           ).astype(np.float32) if len(val) else val
+    a = SparseTensor(rowptr=torch.from_numpy(rowptr).to(DEV), col=torch.from_numpy(col).to(DEV), value=torch.from_numpy(val).to(DEV),
+                     sparse_sizes=(n, n), is_sorted=True)
+    x = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(DEV)
+    ref = ops.khop(a, x, K)
+    for s in (2, 3, 7):
+        assert torch.equal(ops.khop(a, x, K, n_col_slices=s), ref), (case, n, F, K, s)
+    h = x
+    for _ in range(K):
+        h = ops.spmm_raw(a, h, "sum")
+    assert torch.equal(h, ref), "K calls of the one-hop kernel give the same bits as the K-hop entry point"
