@@ -441,3 +441,119 @@ def test_random_khop_column_slices_keep_every_bit(case):
     for _ in range(K):
         h = ops.spmm_raw(a, h, "sum")
     assert torch.equal(h, ref), "K calls of the one-hop kernel give the same bits as the K-hop entry point"
+
+
+def _dense_A(edge_index, n_src, size, w):
+    """(A [n_dst, n_src] float64, entries per row) from a SparseTensor adj_t or an int64 [2, E] edge list + weights."""
+    from disco_amd.models.convs_large.message_passing import as_adj_t
+    adj_t = as_adj_t(edge_index)
+    if adj_t is not None:
+        rowptr, col, val = adj_t.csr()
+        n_dst, n_src = adj_t.sparse_sizes()
+        r = torch.repeat_interleave(torch.arange(n_dst, device=rowptr.device), rowptr.diff())
+        c, vals = col.long(), (None if val is None else val.double())
+    else:
+        n_dst = n_src if size is None or size[1] is None else size[1]
+        r, c, vals = edge_index[1].long(), edge_index[0].long(), (None if w is None else w.double())
+    if vals is None:
+        vals = torch.ones(r.numel(), dtype=torch.float64, device=r.device)
+    A = torch.zeros(n_dst, n_src, dtype=torch.float64, device=r.device).index_put_((r, c), vals, accumulate=True)
+    return A, torch.bincount(r, minlength=n_dst)
+
+
+def _dense_propagate(self, edge_index, size=None, **kw):
+    x = kw.get("x")
+    x = x[0] if isinstance(x, (tuple, list)) else x
+    A, cnt = _dense_A(edge_index, x.shape[0], size, kw.get("edge_weight"))
+    out = A @ x.double()
+    if self.aggr == "mean":
+        out = out / cnt.clamp(min=1).double()[:, None]
+    assert self.aggr != "max"
+    return out
+
+
+@pytest.mark.parametrize("case", list(range(30)))
+def test_random_models_forward_backward_against_dense_float64(case, monkeypatch):
+    """A5 / A6 / A10 callers end to end: a random BasicGNN (family, depth, width, norm, jumping knowledge), a random
+    graph given as [2, E] + weights, [2, E] alone or a SparseTensor adj_t, in train or eval mode -- log-probabilities and
+    every gradient (input and parameters) against the SAME module evaluated in float64 with every propagation replaced
+    by a dense matrix product."""
+    import copy
+    from disco_amd import SparseTensor, ops, utils
+    from disco_amd.models import basicgnn_large as M
+    from disco_amd.models.convs_large import message_passing as mp
+    rng = np.random.default_rng(7000 + case)
+    torch.manual_seed(7000 + case)
+    name = ["GCN", "SGC", "GraphSAGE", "GIN", "JKNet"][case % 5]
+    n = int(rng.choice([40, 300, 1200]))
+    d, nhid, C = int(rng.choice([5, 32, 100])), int(rng.choice([8, 33, 64])), int(rng.choice([2, 7, 40]))
+    nlayers = int(rng.choice([1, 2, 3, 4]))
+    norm = "BatchNorm" if rng.random() < 0.5 else None
+    E = int(n * rng.choice([2, 12]))
+    ei = torch.from_numpy(rng.integers(0, n, (2, E))).to(DEV)
+    ew = torch.from_numpy(rng.random(E).astype(np.float32) + 0.05).to(DEV)
+    if name in ("GCN", "SGC", "JKNet"):
+        ei, ew = utils.gcn_norm(ei, ew, n, add_self_loops=bool(rng.random() < 0.5))
+    kind = int(rng.integers(0, 3))          # 0: [2,E] + weights, 1: [2,E] alone, 2: SparseTensor adj_t
+    train = bool(rng.random() < 0.5)
+    if name == "SGC":
+        model = M.SGC(nfeat=d, nhid=nhid, nclass=C, dropout=0.0, nlayers=max(nlayers, 1), sgc=True)
+    elif name == "JKNet":
+        model = M.JKNet(nfeat=d, nhid=nhid, nclass=C, dropout=0.0, nlayers=max(nlayers, 2), norm=norm, jk=str(rng.choice(["cat", "max"])))
+    else:
+        model = getattr(M, name)(nfeat=d, nhid=nhid, nclass=C, dropout=0.0, nlayers=nlayers, norm=norm)
+    model = model.to(DEV)
+    model.initialize()
+    for m_ in model.modules():
+        if isinstance(m_, torch.nn.BatchNorm1d):
+            with torch.no_grad():
+                m_.running_mean.normal_(0, 0.1)
+                m_.running_var.uniform_(0.5, 1.5)
+    model.train(train)
+    ref_model = copy.deepcopy(model).double()
+    x = torch.randn(n, d, device=DEV)
+    g = torch.randn(n, C, device=DEV)
+
+    def graph():
+        if kind == 2:
+            return SparseTensor(row=ei[1], col=ei[0], value=ew, sparse_sizes=(n, n)), {}
+        return ei, ({"edge_weight": ew} if kind == 0 else {})
+
+    def run(mdl, xin, gin):
+        xin = xin.clone().requires_grad_(True)
+        adj, kw = graph()
+        out = mdl(xin, adj, **kw)
+        (out * gin).sum().backward()
+        grads = {k: p.grad for k, p in mdl.named_parameters() if p.grad is not None}
+        return out.detach(), xin.grad, grads
+
+    out, gx, gp = run(model, x, g)
+    with monkeypatch.context() as mpc:
+        mpc.setattr(mp.MessagePassing, "propagate", _dense_propagate)
+
+        def khop64(adj_t, x_, K, **_):
+            A, _c = _dense_A(adj_t, x_.shape[0], None, None)
+            for _ in range(K):
+                x_ = A @ x_.double()
+            return x_
+        mpc.setattr(ops, "khop", khop64)
+        out64, gx64, gp64 = run(ref_model, x.double(), g.double())
+    what = (case, name, n, d, nhid, C, nlayers, norm, kind, train)
+
+    # a bias in front of a BatchNorm in train mode has gradient 0 exactly; float32 leaves rounding noise there, which is
+    # measured against the largest parameter gradient instead of against 0
+    gscale = max(float(v.abs().max()) for v in gp64.values())
+
+    def close(a, b, tag, tol=2e-4):
+        scale = float(b.abs().max()) + 1e-6
+        if tag.startswith("d/d") and tag != "d/dx":
+            scale = max(scale, 1e-2 * gscale)
+        err = float((a.double() - b).abs().max())
+        assert err <= tol * scale, f"{what} {tag}: {err:.3e} vs scale {scale:.3e}"
+
+    assert torch.isfinite(out).all()
+    close(out, out64, "log-probabilities")
+    close(gx, gx64, "d/dx")
+    assert set(gp) == set(gp64), what
+    for k in gp:
+        close(gp[k], gp64[k], "d/d" + k, tol=5e-4)
