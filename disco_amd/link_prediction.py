@@ -116,4 +116,4 @@ def link_prediction(pge_edge, feat_transform: torch.Tensor, edge_index: torch.Te
                 print("Acc:", acc)
     if int(err.item()):
         raise IndexError("link_prediction: an edge index pointed outside feat_transform")
-    return best_acc, (float(loss) if loss is not None else None)
+    return best_acc, (float(loss.detach()) if loss is not None else None)
