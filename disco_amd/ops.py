@@ -151,6 +151,8 @@ def khop(adj: SparseTensor, x: torch.Tensor, K: int, n_col_slices: int = 1, out:
     t1 = scratch[n * ldt: 2 * n * ldt] if ntmp >= 2 else None
     lib = _lib.load()
     val = adj._value
+    if val is not None and val.dtype != torch.float32:      # the kernels read float32 values (as spmm_raw)
+        val = val.to(torch.float32)
     with torch.cuda.device(x.device):
         stream = _lib.current_stream(x.device)
         ws_ptr, info_ref, sws, sws_bytes = None, None, None, 0

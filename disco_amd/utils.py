@@ -201,6 +201,8 @@ def normalize_adj_csr(adj: SparseTensor) -> SparseTensor:
         # Structure of mx + I: a zero-valued diagonal entry is merged into every row (x + 0 is exact in
         # float32); the kernels add the 1 in float64, as scipy's `mx + sp.eye(n)` does.
         adj = _with_diagonal(adj, row, col, val.to(torch.float32).contiguous())
+    elif adj._value is not None and adj._value.dtype != torch.float32:
+        adj = adj.set_value(adj._value.to(torch.float32))       # the kernels read float32 values
     lib = _lib.load()
     with torch.cuda.device(adj.device):
         s = _lib.current_stream(adj.device)

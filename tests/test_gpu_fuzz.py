@@ -557,3 +557,34 @@ def test_random_models_forward_backward_against_dense_float64(case, monkeypatch)
     assert set(gp) == set(gp64), what
     for k in gp:
         close(gp[k], gp64[k], "d/d" + k, tol=5e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float16, torch.int64])
+def test_values_of_another_dtype_are_read_as_numbers_not_as_bytes(dtype):
+    """A SparseTensor may carry float64 (scipy's default), half or integer values; every entry point that hands the
+    value array to a float32 kernel converts it first (one of them, the K-hop call, used to pass the raw pointer)."""
+    from disco_amd import SparseTensor, ops, utils
+    rng = np.random.default_rng(11)
+    n, F = 500, 40
+    rowptr, col, val = random_csr(n, n, 6, seed=11, hubs=[], weighted=True, dup=False)
+    v32 = torch.from_numpy(np.round(np.abs(val) * 4 + 1).astype(np.float32)).to(DEV)      # small integers: exact in every dtype
+    mk = lambda v: SparseTensor(rowptr=torch.from_numpy(rowptr).to(DEV), col=torch.from_numpy(col).to(DEV), value=v,
+                                sparse_sizes=(n, n), is_sorted=True)
+    a32, a = mk(v32), mk(v32.to(dtype))
+    x = torch.from_numpy(rng.standard_normal((n, F)).astype(np.float32)).to(DEV)
+    assert torch.equal(ops.spmm_raw(a, x, "sum"), ops.spmm_raw(a32, x, "sum"))
+    assert torch.equal(ops.khop(a, x, 2), ops.khop(a32, x, 2))
+    assert torch.equal(ops.spmm_raw(a.t(), x, "sum"), ops.spmm_raw(a32.t(), x, "sum"))
+    for with00 in (False, True):
+        if with00:      # mx[0,0] != 0: normalize_adj adds no identity and reads the values as they are
+            r = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), a32.coo()[0]])
+            c = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), a32.coo()[1]])
+            keep = torch.ones(r.numel(), dtype=torch.bool, device=DEV)
+            keep[1:] = ~((r[1:] == 0) & (c[1:] == 0))
+            vv = torch.cat([torch.full((1,), 3.0, device=DEV), v32])[keep]
+            b32 = SparseTensor(row=r[keep], col=c[keep], value=vv, sparse_sizes=(n, n))
+            b = b32.set_value(b32.storage.value().to(dtype))
+        else:
+            b32, b = a32, a
+        assert torch.equal(utils.normalize_adj_csr(b).storage.value(), utils.normalize_adj_csr(b32).storage.value()), with00
+    assert torch.equal(utils.gcn_norm(a, add_self_loops=False).storage.value(), utils.gcn_norm(a32, add_self_loops=False).storage.value())
