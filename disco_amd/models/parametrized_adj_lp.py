@@ -94,7 +94,10 @@ class PGE_Edge(nn.Module):
         i0, i1 = rows
         j0, j1 = cols if cols is not None else (0, n)
         if out is None:
-            out = torch.empty((i1 - i0, j1 - j0), dtype=torch.float32, device=Z.device)
+            out = torch.empty((max(i1 - i0, 0), max(j1 - j0, 0)), dtype=torch.float32, device=Z.device)
+        elif (tuple(out.shape) != (i1 - i0, j1 - j0) or out.dtype != torch.float32 or out.device != Z.device
+              or (out.numel() and out.stride(1) != 1)):
+            raise ValueError(f"out must be a float32 [{i1 - i0}, {j1 - j0}] tensor on {Z.device} with unit column stride")
         lib = _lib.load()
         with torch.cuda.device(Z.device):
             _lib.check(lib.disco_pairscore_block_f32(_lib.ptr(ws), n, H, i0, i1, j0, j1, _lib.ptr(out), out.stride(0),
@@ -161,6 +164,10 @@ class PGE_Edge(nn.Module):
         """Symmetrise / threshold / unit diagonal / ``nonzero`` of a full score matrix (the tail of the three
         ``edge_construction`` variants), ``disco_sym_threshold_count/fill``."""
         v = _VARIANTS[variant]
+        if S.dim() != 2 or S.shape[0] != S.shape[1] or S.dtype != torch.float32 or S.device.type != "cuda":
+            raise ValueError("S must be a square float32 score matrix on the GPU")
+        if S.numel() and S.stride(1) != 1:
+            S = S.contiguous()
         Z = S
         n = S.shape[0]
         lib = _lib.load()

@@ -50,6 +50,15 @@ def _padded_empty(n: int, F: int, device, pad: int = 4) -> torch.Tensor:
     return torch.empty((n, ld), dtype=torch.float32, device=device)[:, :F]
 
 
+def _check_out(out: torch.Tensor, n: int, F: int, device, what: str) -> None:
+    """The kernels write n rows of F floats at out.stride(0): a buffer of another shape, type or place would be
+    overrun silently."""
+    if (out.dim() != 2 or out.shape[0] != n or out.shape[1] != F or out.dtype != torch.float32 or out.device != device
+            or (F > 1 and out.stride(1) != 1) or (n > 1 and out.stride(0) < F)):
+        raise ValueError(f"{what}: out must be a float32 [{n}, {F}] tensor on {device} with unit column stride, got "
+                         f"{tuple(out.shape)} {out.dtype} on {out.device}, strides {tuple(out.stride())}")
+
+
 def _hub_workspace(adj: SparseTensor, info, F: int, lib, device):
     """Partial-row workspace of the hub kernels, kept on the adjacency and grown on demand (one allocation per
     graph instead of one per call).  Calls that overlap on different streams must not share an adjacency."""
@@ -74,6 +83,8 @@ def spmm_raw(adj: SparseTensor, x: torch.Tensor, reduce: str = "sum", out: Optio
     F = x.shape[1]
     if out is None:
         out = _padded_empty(n, F, x.device)
+    else:
+        _check_out(out, n, F, x.device, "spmm_raw")
     lib = _lib.load()
     val = adj._value
     if val is not None and val.dtype != torch.float32:
@@ -140,8 +151,14 @@ def khop(adj: SparseTensor, x: torch.Tensor, K: int, n_col_slices: int = 1, out:
     if n != m or x.shape[0] != n:
         raise ValueError("khop needs a square adjacency matching x")
     F = x.shape[1]
+    if K < 1:
+        raise ValueError("khop needs K >= 1")
     if out is None:
         out = _padded_empty(n, F, x.device)
+    else:
+        _check_out(out, n, F, x.device, "khop")
+    if scratch is not None and (scratch.dtype != torch.float32 or scratch.device != x.device or not scratch.is_contiguous()):
+        raise ValueError("khop: scratch must be a contiguous float32 buffer on the features' device")
     ldt = (F + 31) // 32 * 32
     ntmp = min(K - 1, 2)
     need = ntmp * n * ldt

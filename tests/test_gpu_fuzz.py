@@ -588,3 +588,40 @@ def test_values_of_another_dtype_are_read_as_numbers_not_as_bytes(dtype):
             b32, b = a32, a
         assert torch.equal(utils.normalize_adj_csr(b).storage.value(), utils.normalize_adj_csr(b32).storage.value()), with00
     assert torch.equal(utils.gcn_norm(a, add_self_loops=False).storage.value(), utils.gcn_norm(a32, add_self_loops=False).storage.value())
+
+
+def test_wrong_output_buffers_are_refused_before_any_launch():
+    """An `out` / `scratch` of the wrong shape, type, stride or device would be overrun by the kernels: refused in Python."""
+    from disco_amd import SparseTensor, ops
+    from disco_amd.models.parametrized_adj_lp import PGE_Edge
+    n, F = 50, 12
+    rowptr, col, val = random_csr(n, n, 4, seed=3, hubs=[], weighted=True, dup=False)
+    a = SparseTensor(rowptr=torch.from_numpy(rowptr).to(DEV), col=torch.from_numpy(col).to(DEV), value=torch.from_numpy(val).to(DEV),
+                     sparse_sizes=(n, n), is_sorted=True)
+    x = torch.randn(n, F, device=DEV)
+    bad = [torch.empty(n - 1, F, device=DEV), torch.empty(n, F - 1, device=DEV), torch.empty(n, F, device=DEV, dtype=torch.float64),
+           torch.empty(F, n, device=DEV).t(), torch.empty(n, F), torch.empty(n * F, device=DEV)]
+    for out in bad:
+        with pytest.raises((ValueError, RuntimeError)):
+            ops.spmm_raw(a, x, "sum", out=out)
+        with pytest.raises((ValueError, RuntimeError)):
+            ops.khop(a, x, 2, out=out)
+    with pytest.raises(ValueError):
+        ops.khop(a, x, 0)
+    with pytest.raises(ValueError):
+        ops.khop(a, x, 3, scratch=torch.empty(4 * n * 32, device=DEV, dtype=torch.float64))
+    good = torch.full((n, 16), 5.0, device=DEV)
+    ops.khop(a, x, 3, out=good[:, :F], scratch=torch.empty(2 * n * 32, device=DEV))
+    assert torch.equal(good[:, :F], ops.khop(a, x, 3)) and bool((good[:, F:] == 5.0).all())
+    m = PGE_Edge(nfeat=F, nhid=32, nlayers=3).to(DEV)
+    Z = torch.randn(n, F, device=DEV)
+    for out in (torch.empty(4, n, device=DEV), torch.empty(5, n - 1, device=DEV), torch.empty(5, n, device=DEV, dtype=torch.float64),
+                torch.empty(n, 5, device=DEV).t()):
+        with pytest.raises(ValueError):
+            m.score_block(Z, (0, 5), out=out)
+    with pytest.raises(ValueError):
+        m.edges_from_scores(torch.zeros(4, 5, device=DEV), 0.5)
+    S = m.score_all_pairs(Z)
+    e1 = m.edges_from_scores(S, 0.5)
+    e2 = m.edges_from_scores(S.t().contiguous().t(), 0.5)          # column-major view of the same matrix: copied, same edges
+    assert torch.equal(e1[0], e2[0]) and torch.equal(e1[1], e2[1])

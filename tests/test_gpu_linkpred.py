@@ -68,7 +68,7 @@ def _reference_style_loop(pge, feat_transform, edge_index, neg_edge_index, nedge
         loss = torch.nn.BCELoss()(pred, y.float())
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     return losses
 
 
