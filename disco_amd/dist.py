@@ -190,7 +190,9 @@ class RowPartition:
     def _spmm_dense(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         """All-gather of the X shards, pipelined by column chunk: chunk c + 1 is on the wire while the halo SpMM of
         chunk c runs, so only the first chunk's transfer (and what the SpMMs cannot cover) is exposed.  Every output
-        column still gets interior first, halo second: the bits do not depend on the chunking."""
+        column still gets interior first, halo second: below the hub threshold the bits do not depend on the chunking
+        (a hub row's pieces are summed by 512 / G lane groups, and G follows the chunk's width: last-bit differences
+        there once F exceeds one chunk)."""
         F, n = x.shape[1], self.n_local
         chunks = self._col_chunks(F)
         if self._dense_key != (F, len(chunks), x.dtype, x.device):
