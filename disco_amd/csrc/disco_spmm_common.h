@@ -144,6 +144,15 @@ __device__ __forceinline__ typename Vec<VEC>::type gather_vec(const float* __res
 #if defined(DISCO_DBG_NOGATHER)
   { V r; r = (float)c * 1e-9f + (float)off; return r; }
 #endif
+#if defined(DISCO_GATHER_AUX)
+  // experiment (tools/r3/exp_gather_policy.sh): 128-bit gathers through a buffer descriptor with cache-policy bits
+  //   aux 0 plain, 1 sc0, 2 nt, 16 sc1, 17 sc0 sc1 -- does a gather that does not allocate in the L1 go faster?
+  if constexpr (A24 && VEC == 4) {
+    const uint32_t bo = __umul24((uint32_t)c, (uint32_t)ldx * 4u) + (uint32_t)off * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0xffffffff, 0x27000);
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)bo, 0, DISCO_GATHER_AUX));
+  }
+#endif
 #if defined(DISCO_GATHER_NT)
   // experiment: every gather carries `nt` (does the hint change what the L2 retains?  profiles/r2/gather_nt.log)
   if constexpr (A24) {
