@@ -69,3 +69,18 @@ def test_argument_validation_of_the_set_up_entry_points():
     assert lib.disco_pair_gather_f32(None, 10, 8, 8, None, None, None, 5, 5, None, 16, None, None) == -1
     # scorer: unsupported hidden width
     assert lib.disco_pairscore_workspace_bytes(-1, 256) == 0
+
+
+def test_tuning_defaults_of_the_test_fixture_cover_every_key():
+    """tests/conftest.py restores every tuning key after each GPU test: its list must name exactly the keys
+    disco_set_tuning accepts, and every one of them must be accepted by the built library."""
+    import re
+    from conftest import _TUNING_DEFAULTS
+    src = open(os.path.join(ROOT, "disco_amd", "csrc", "disco_norm.hip")).read()
+    keys = set(re.findall(r'strcmp\(key, "(\w+)"\)', src))
+    assert keys == set(_TUNING_DEFAULTS), keys ^ set(_TUNING_DEFAULTS)
+    from disco_amd.build import lib_path
+    lib = ctypes.CDLL(lib_path())
+    lib.disco_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    for k, v in _TUNING_DEFAULTS.items():
+        assert lib.disco_set_tuning(k.encode(), v) == 0
