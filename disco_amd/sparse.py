@@ -53,6 +53,8 @@ def coo_to_csr(row: torch.Tensor, col: torch.Tensor, value: Optional[torch.Tenso
     col = col.to(torch.int64).contiguous()
     if value is not None and value.dtype != torch.float32:
         raise TypeError("coo_to_csr carries float32 values")
+    if value is not None:
+        value = value.contiguous()           # kept alive in this frame until the call below has been enqueued
     want_value = (value is not None) if want_value is None else want_value
     e, (m, n) = int(row.numel()), sparse_sizes
     cap = 2 * e if symmetrise else e
@@ -65,7 +67,7 @@ def coo_to_csr(row: torch.Tensor, col: torch.Tensor, value: Optional[torch.Tenso
         val_out = torch.empty(max(cap, 1), dtype=torch.float32, device=dev) if want_value else None
         import ctypes
         nnz = ctypes.c_int64(0)
-        _lib.check(lib.disco_coo_to_csr(_lib.ptr(row), _lib.ptr(col), _lib.ptr(value.contiguous()) if value is not None else None,
+        _lib.check(lib.disco_coo_to_csr(_lib.ptr(row), _lib.ptr(col), _lib.ptr(value),
                                         e, m, n, flags, _lib.ptr(rowptr), _lib.ptr(col_out), _lib.ptr(val_out),
                                         ctypes.byref(nnz), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
                    "disco_coo_to_csr")
