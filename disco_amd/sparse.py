@@ -159,6 +159,7 @@ class SparseTensor:
         self._hub_ws: Optional[torch.Tensor] = None    # partial-row workspace of the hub kernels (grown on demand)
         self._row_groups: Optional[torch.Tensor] = None   # locality groups: major key of the row order
         self._t: Optional["SparseTensor"] = None
+        self._on_device = {}        # host-resident object: its device copies, one per GPU (see to())
         self._shared = _StructCache()
         self.storage = _Storage(self)
 
@@ -269,10 +270,20 @@ class SparseTensor:
         device = torch.device(device) if not isinstance(device, torch.device) else device
         if device == self.device or (device.type == "cuda" and device.index is None and self.device.type == "cuda"):
             return self
+        # The reference keeps `adj` on the host and writes `adj.to(device)` in front of each of its 31 evaluations
+        # (/root/reference/LargeScaleCondensing.py:344): the first call uploads, later calls return the SAME device object,
+        # with its schedule and transpose already built (the graph stays resident).  The structure of a
+        # SparseTensor is immutable (set_value makes a new object), so the copy cannot go stale.
+        host_to_gpu = self.device.type == "cpu" and device.type == "cuda"
+        key = device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else -1)
+        if host_to_gpu and key in self._on_device:
+            return self._on_device[key]
         out = SparseTensor(rowptr=self._rowptr.to(device, non_blocking=non_blocking),
                            col=self._col32.to(device, non_blocking=non_blocking),
                            value=None if self._value is None else self._value.to(device, non_blocking=non_blocking),
                            sparse_sizes=self._sizes, is_sorted=True)
+        if host_to_gpu:
+            self._on_device[key] = out
         return out
 
     def cuda(self) -> "SparseTensor":

@@ -280,3 +280,29 @@ def test_forward_sampler_equals_full_graph_forward_and_backward(model_name, trai
     assert set(gp1) == set(gp2)
     for k in gp1:
         assert torch.allclose(gp1[k], gp2[k], rtol=1e-3, atol=1e-4), k
+
+
+def test_host_resident_adjacency_is_uploaded_once():
+    """The reference keeps `adj` on the host and calls `adj.to(device)` before each of its 31 evaluations
+    (LargeScaleCondensing.py:344, :486): the first call uploads, the others return the same device object (schedule kept)."""
+    from disco_amd import SparseTensor
+    from disco_amd.models import basicgnn_large as M
+    n, d = 300, 16
+    rowptr, col, val = make_graph(n, seed=21)
+    r, c = csr_to_coo(rowptr, col)
+    # as the driver builds it: SparseTensor(row=, col=, value=, sparse_sizes=).t() from host tensors, transposed back here
+    host = SparseTensor(row=torch.from_numpy(c), col=torch.from_numpy(r), value=torch.from_numpy(val), sparse_sizes=(n, n)).t()
+    assert host.device.type == "cpu"
+    dev1 = host.to(DEV)
+    assert dev1.device.type == "cuda" and host.to(DEV) is dev1 and host.cuda() is dev1 and host.to(torch.device(DEV)) is dev1
+    assert dev1.to(DEV) is dev1 and dev1.cpu().device.type == "cpu"
+    model = M.SGC(nfeat=d, nhid=8, nclass=3, nlayers=2, sgc=True).to(DEV)
+    x = torch.randn(n, d, device=DEV)
+    out1 = model.predict(x, host.to(DEV))
+    sched = dev1._sched
+    out2 = model.predict(x, host.to(DEV))
+    assert dev1._sched is sched and sched is not None and torch.equal(out1, out2)
+    ref = model.predict(x, to_adj(rowptr, col, val, n))
+    assert torch.allclose(out1, ref, rtol=1e-5, atol=1e-6)
+    other = host.set_value(torch.from_numpy(val * 2))          # other values: a new object with its own device copy
+    assert other.to(DEV) is not dev1 and torch.equal(other.to(DEV).storage.value(), dev1.storage.value() * 2)
