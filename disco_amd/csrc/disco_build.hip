@@ -28,7 +28,7 @@ static inline int bits_for(int64_t n) { int b = 1; while (b < 63 && ((int64_t)1 
 __global__ void k_coo_keys(const int64_t* __restrict__ row, const int64_t* __restrict__ col, const float* __restrict__ val,
                            int64_t n_edges, int64_t n_rows, int64_t n_cols, int cbits, int sym,
                            uint64_t* __restrict__ keys, float* __restrict__ pay, unsigned long long* bad) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t i = block_id() * blockDim.x + threadIdx.x;
   bool oob = false;
   if (i < n_edges) {
     int64_t r = row[i], c = col[i];
@@ -47,7 +47,7 @@ __global__ void k_coo_keys(const int64_t* __restrict__ row, const int64_t* __res
 }
 
 __global__ void k_run_heads(const uint64_t* __restrict__ keys, int64_t m, int64_t* __restrict__ head) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t i = block_id() * blockDim.x + threadIdx.x;
   if (i < m) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
 
@@ -55,7 +55,7 @@ __global__ void k_run_heads(const uint64_t* __restrict__ keys, int64_t m, int64_
 __global__ void k_fold_runs(const uint64_t* __restrict__ keys, const float* __restrict__ pay, const int64_t* __restrict__ pos,
                             int64_t m, int cbits, int first_only, uint64_t* __restrict__ ukeys, int32_t* __restrict__ col_out,
                             float* __restrict__ val_out, int64_t* __restrict__ nnz_dev) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t i = block_id() * blockDim.x + threadIdx.x;
   if (i >= m) return;
   uint64_t k = keys[i];
   bool head = i == 0 || keys[i - 1] != k;
@@ -76,14 +76,14 @@ __global__ void k_fold_runs(const uint64_t* __restrict__ keys, const float* __re
 }
 
 __global__ void k_keep_all(const uint64_t* __restrict__ keys, int64_t m, int cbits, int32_t* __restrict__ col_out) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t i = block_id() * blockDim.x + threadIdx.x;
   if (i < m) col_out[i] = (int32_t)(keys[i] & (((uint64_t)1 << cbits) - 1));
 }
 
 // rowptr[r] = number of (unique) keys below (r << cbits); *count is the device-side entry count
 __global__ void k_rowptr_search(const uint64_t* __restrict__ keys, const int64_t* __restrict__ count, int64_t fixed_count,
                                 int64_t n_rows, int cbits, int64_t* __restrict__ rowptr) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t r = block_id() * blockDim.x + threadIdx.x;
   if (r > n_rows) return;
   int64_t n = count ? *count : fixed_count;
   uint64_t target = (uint64_t)r << cbits;
@@ -181,9 +181,10 @@ extern "C" int disco_coo_to_csr(const int64_t* row, const int64_t* col, const fl
   void* tmp = ws + L.off_tmp;
 
   DISCO_HIP_TRY(hipMemsetAsync(ws + L.off_cnt, 0, 64, stream));
-  unsigned eb = (unsigned)((n_edges + 255) / 256), mb = (unsigned)((L.m + 255) / 256);
-  if ((n_edges + 255) / 256 > 0x7fffffffLL || (L.m + 255) / 256 > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_coo_keys, dim3(eb), dim3(256), 0, stream, row, col, val, n_edges, n_rows, n_cols, cbits, sym ? 1 : 0,
+  DISCO_GRID(eb, (n_edges + 255) / 256, 256);
+  DISCO_GRID(mb, (L.m + 255) / 256, 256);
+  DISCO_GRID(rb, (n_rows + 256) / 256, 256);
+  hipLaunchKernelGGL(k_coo_keys, eb, dim3(256), 0, stream, row, col, val, n_edges, n_rows, n_cols, cbits, sym ? 1 : 0,
                      keys_a, pay_a, bad);
   DISCO_CHECK_LAUNCH();
   size_t st = L.sort_tmp;
@@ -194,25 +195,25 @@ extern "C" int disco_coo_to_csr(const int64_t* row, const int64_t* col, const fl
     DISCO_HIP_TRY(rocprim::radix_sort_keys(tmp, st, (const uint64_t*)keys_a, keys_b, (size_t)L.m, 0, (unsigned)(cbits + rbits),
                                            stream));
   if (dup == DISCO_COO_DUP_KEEP) {
-    hipLaunchKernelGGL(k_keep_all, dim3(mb), dim3(256), 0, stream, (const uint64_t*)keys_b, L.m, cbits, col_out);
+    hipLaunchKernelGGL(k_keep_all, mb, dim3(256), 0, stream, (const uint64_t*)keys_b, L.m, cbits, col_out);
     DISCO_CHECK_LAUNCH();
     if (with_val) DISCO_HIP_TRY(hipMemcpyAsync(val_out, pay_b, 4 * (size_t)L.m, hipMemcpyDeviceToDevice, stream));
-    hipLaunchKernelGGL(k_rowptr_search, dim3((unsigned)((n_rows + 256) / 256)), dim3(256), 0, stream, (const uint64_t*)keys_b,
+    hipLaunchKernelGGL(k_rowptr_search, rb, dim3(256), 0, stream, (const uint64_t*)keys_b,
                        (const int64_t*)nullptr, L.m, n_rows, cbits, rowptr);
     DISCO_CHECK_LAUNCH();
   } else {
     int64_t* head = reinterpret_cast<int64_t*>(ws + L.off_head);
     int64_t* pos = reinterpret_cast<int64_t*>(ws + L.off_pos);
-    hipLaunchKernelGGL(k_run_heads, dim3(mb), dim3(256), 0, stream, (const uint64_t*)keys_b, L.m, head);
+    hipLaunchKernelGGL(k_run_heads, mb, dim3(256), 0, stream, (const uint64_t*)keys_b, L.m, head);
     DISCO_CHECK_LAUNCH();
     size_t sc = L.scan_tmp;
     DISCO_HIP_TRY(rocprim::exclusive_scan(tmp, sc, (const int64_t*)head, pos, (int64_t)0, (size_t)L.m, rocprim::plus<int64_t>(),
                                           stream));
     // unique keys go back into keys_a (no longer needed)
-    hipLaunchKernelGGL(k_fold_runs, dim3(mb), dim3(256), 0, stream, (const uint64_t*)keys_b, (const float*)pay_b,
+    hipLaunchKernelGGL(k_fold_runs, mb, dim3(256), 0, stream, (const uint64_t*)keys_b, (const float*)pay_b,
                        (const int64_t*)pos, L.m, cbits, dup == DISCO_COO_DUP_FIRST ? 1 : 0, keys_a, col_out, val_out, nnz_dev);
     DISCO_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_rowptr_search, dim3((unsigned)((n_rows + 256) / 256)), dim3(256), 0, stream, (const uint64_t*)keys_a,
+    hipLaunchKernelGGL(k_rowptr_search, rb, dim3(256), 0, stream, (const uint64_t*)keys_a,
                        (const int64_t*)nnz_dev, (int64_t)0, n_rows, cbits, rowptr);
     DISCO_CHECK_LAUNCH();
   }
@@ -234,7 +235,7 @@ namespace disco {
 
 __global__ void k_diag_probe(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n,
                              int64_t* __restrict__ missing, int64_t* __restrict__ dpos) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = block_id() * blockDim.x + threadIdx.x;
   if (r > n) return;
   if (r == n) { missing[r] = 0; dpos[r] = rowptr[n]; return; }
   int64_t lo = rowptr[r], hi = rowptr[r + 1];
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void k_diag_insert(const int64_t* __restrict__
                                                      const int64_t* __restrict__ dpos, int64_t* __restrict__ rowptr_out,
                                                      int32_t* __restrict__ col_out, float* __restrict__ val_out) {
   // rows: new row pointers and the inserted diagonal entries (grid-stride over rows)
-  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= n; r += (int64_t)gridDim.x * 256) {
+  for (int64_t r = block_id() * 256 + threadIdx.x; r <= n; r += (int64_t)gridDim.x * gridDim.y * 256) {
     rowptr_out[r] = rowptr[r] + shift[r];
     if (r < n && missing[r]) {
       const int64_t p = dpos[r] + shift[r];
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void k_diag_insert(const int64_t* __restrict__
     }
   }
   // entries: this workgroup's chunk, rows found by binary search inside the chunk's row range
-  const int64_t c0 = (int64_t)blockIdx.x * kInsChunk;
+  const int64_t c0 = block_id() * kInsChunk;
   const int64_t c1 = c0 + kInsChunk < nnz ? c0 + kInsChunk : nnz;
   if (c0 >= c1) return;
   auto row_of = [&](int64_t lo, int64_t hi, int64_t i) {
@@ -313,15 +314,16 @@ extern "C" int disco_csr_insert_diagonal(const int64_t* rowptr, const int32_t* c
   int64_t* shift = reinterpret_cast<int64_t*>(ws + slot);
   int64_t* dpos = reinterpret_cast<int64_t*>(ws + 2 * slot);
   void* tmp = ws + 3 * slot;
-  hipLaunchKernelGGL(k_diag_probe, dim3((unsigned)((n_rows + 256) / 256)), dim3(256), 0, stream, rowptr, col, n_rows, missing, dpos);
+  DISCO_GRID(g_probe, (n_rows + 256) / 256, 256);
+  hipLaunchKernelGGL(k_diag_probe, g_probe, dim3(256), 0, stream, rowptr, col, n_rows, missing, dpos);
   DISCO_CHECK_LAUNCH();
   DISCO_HIP_TRY(rocprim::exclusive_scan(tmp, scan_tmp, (const int64_t*)missing, shift, (int64_t)0, (size_t)(n_rows + 1),
                                         rocprim::plus<int64_t>(), stream));
   int64_t blocks = (nnz + kInsChunk - 1) / kInsChunk;
   const int64_t row_blocks = (n_rows + 256) / 256 < 4096 ? (n_rows + 256) / 256 : 4096;
   if (blocks < row_blocks) blocks = row_blocks;
-  if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_diag_insert, dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, val, n_rows, nnz,
+  DISCO_GRID(g_ins, blocks, 256);
+  hipLaunchKernelGGL(k_diag_insert, g_ins, dim3(256), 0, stream, rowptr, col, val, n_rows, nnz,
                      (const int64_t*)missing, (const int64_t*)shift, (const int64_t*)dpos, rowptr_out, col_out, val_out);
   DISCO_CHECK_LAUNCH();
   int64_t added = 0;
@@ -337,14 +339,14 @@ extern "C" int disco_csr_insert_diagonal(const int64_t* rowptr, const int32_t* c
 namespace disco {
 
 __global__ __launch_bounds__(256) void k_ids_to_u32(const int64_t* __restrict__ idx, int64_t E, int64_t N, uint32_t* __restrict__ key) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = block_id() * 256 + threadIdx.x;
   if (i >= E) return;
   const int64_t v = idx[i];
   key[i] = (v >= 0 && v < N) ? (uint32_t)v : (uint32_t)N;      // ids outside [0, N) sort behind every node and are ignored
 }
 
 __global__ __launch_bounds__(256) void k_zero_f32(float* __restrict__ p, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = block_id() * 256 + threadIdx.x;
   if (i < n) p[i] = 0.0f;
 }
 
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256) void k_zero_f32(float* __restrict__ p, int64_t
 // version does (uint32 -> float32).  Nodes without a run keep the zero k_zero_f32 wrote.
 __global__ __launch_bounds__(256) void k_run_bounds(const uint32_t* __restrict__ key, int64_t E, int64_t N,
                                                     uint32_t* __restrict__ first, uint32_t* __restrict__ last) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = block_id() * 256 + threadIdx.x;
   if (i >= E) return;
   const uint32_t k = key[i];
   if ((int64_t)k >= N) return;
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256) void k_run_bounds(const uint32_t* __restrict__
 }
 
 __global__ __launch_bounds__(256) void k_run_counts(const uint32_t* __restrict__ first, float* __restrict__ deg, int64_t N) {
-  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t k = block_id() * 256 + threadIdx.x;
   if (k >= N) return;
   const uint32_t end = __float_as_uint(deg[k]);                // 0: no entry names this node
   deg[k] = end ? (float)(end - first[k]) : 0.0f;
@@ -403,22 +405,23 @@ extern "C" int disco_degree_count_sorted_f32(const int64_t* idx, int64_t E, int6
   int rc = deg_layout(E, N, L);
   if (rc != DISCO_OK) return rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, deg, N);
+  DISCO_GRID(nb, (N + 255) / 256, 256);
+  DISCO_GRID(eb, (E + 255) / 256, 256);
+  hipLaunchKernelGGL(k_zero_f32, nb, dim3(256), 0, stream, deg, N);
   DISCO_CHECK_LAUNCH();
   if (E == 0) return DISCO_OK;
   if (!workspace || workspace_bytes < L.total) return DISCO_EWORKSPACE;
   char* ws = static_cast<char*>(workspace);
   uint32_t* a = reinterpret_cast<uint32_t*>(ws + L.off_a);
   uint32_t* b = reinterpret_cast<uint32_t*>(ws + L.off_b);
-  const unsigned eb = (unsigned)((E + 255) / 256);
-  hipLaunchKernelGGL(k_ids_to_u32, dim3(eb), dim3(256), 0, stream, idx, E, N, a);
+  hipLaunchKernelGGL(k_ids_to_u32, eb, dim3(256), 0, stream, idx, E, N, a);
   DISCO_CHECK_LAUNCH();
   size_t st = L.sort_tmp;
   DISCO_HIP_TRY(rocprim::radix_sort_keys(ws + L.off_tmp, st, (const uint32_t*)a, b, (size_t)E, 0, (unsigned)L.bits, stream));
   uint32_t* first = reinterpret_cast<uint32_t*>(ws + L.off_first);
-  hipLaunchKernelGGL(k_run_bounds, dim3(eb), dim3(256), 0, stream, (const uint32_t*)b, E, N, first, reinterpret_cast<uint32_t*>(deg));
+  hipLaunchKernelGGL(k_run_bounds, eb, dim3(256), 0, stream, (const uint32_t*)b, E, N, first, reinterpret_cast<uint32_t*>(deg));
   DISCO_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_run_counts, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)first, deg, N);
+  hipLaunchKernelGGL(k_run_counts, nb, dim3(256), 0, stream, (const uint32_t*)first, deg, N);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
 }

@@ -17,7 +17,7 @@ __global__ void k_pair_gather(const float* __restrict__ Z, int64_t n, int64_t ld
                               const int64_t* __restrict__ sel, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
                               int64_t n_edges, int64_t P, float* __restrict__ out, int64_t ldo, int* __restrict__ err) {
   constexpr int VW = sizeof(V) / 4;
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t t = block_id() * blockDim.x + threadIdx.x;
   int64_t per_pair = 2 * (int64_t)wv;
   if (t >= P * per_pair) return;
   int64_t p = t / per_pair;
@@ -43,7 +43,7 @@ template <typename V>
 __global__ void k_gather_rows(const float* __restrict__ x, int64_t ldx, int wv, const int64_t* __restrict__ idx, int64_t n_idx,
                               float* __restrict__ out, int64_t ldo) {
   constexpr int VW = sizeof(V) / 4;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = block_id() * blockDim.x + threadIdx.x;
   if (t >= n_idx * wv) return;
   const int64_t i = t / wv;
   const int k = (int)(t - i * wv);
@@ -62,7 +62,7 @@ __global__ void k_anchor_max(const float* __restrict__ T, int64_t n, int64_t ldt
                              const int64_t* __restrict__ out_rows, int64_t n_dst, float* __restrict__ out, int64_t ldo,
                              int* __restrict__ err) {
   constexpr int VW = sizeof(V) / 4;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = block_id() * blockDim.x + threadIdx.x;
   if (t >= n_out * wv) return;
   const int64_t i = t / wv;
   const int c = (int)(t - i * wv);
@@ -116,17 +116,18 @@ extern "C" int disco_anchor_max_f32(const float* T, int64_t n, int64_t ldt, int6
   const int vw = aligned(4) ? 4 : aligned(2) ? 2 : 1;
   const int64_t wv = width / vw;
   const int64_t blocks = (n_out * wv + 255) / 256;
-  if (blocks > 0x7fffffffLL || wv > 0x3fffffff) return DISCO_EUNSUPPORTED;
+  if (wv > 0x3fffffff) return DISCO_EUNSUPPORTED;
+  DISCO_GRID(grid, blocks, 256);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int64_t* rm = n_map > 0 ? row_map : nullptr;
   if (vw == 4)
-    hipLaunchKernelGGL(k_anchor_max<float4>, dim3((unsigned)blocks), dim3(256), 0, stream, T, n, ldt, (int)wv, rm, n_map, anchor, n_out,
+    hipLaunchKernelGGL(k_anchor_max<float4>, grid, dim3(256), 0, stream, T, n, ldt, (int)wv, rm, n_map, anchor, n_out,
                        (int)k, out_rows, n_dst, out, ldo, err_flag);
   else if (vw == 2)
-    hipLaunchKernelGGL(k_anchor_max<float2>, dim3((unsigned)blocks), dim3(256), 0, stream, T, n, ldt, (int)wv, rm, n_map, anchor, n_out,
+    hipLaunchKernelGGL(k_anchor_max<float2>, grid, dim3(256), 0, stream, T, n, ldt, (int)wv, rm, n_map, anchor, n_out,
                        (int)k, out_rows, n_dst, out, ldo, err_flag);
   else
-    hipLaunchKernelGGL(k_anchor_max<float>, dim3((unsigned)blocks), dim3(256), 0, stream, T, n, ldt, (int)wv, rm, n_map, anchor, n_out,
+    hipLaunchKernelGGL(k_anchor_max<float>, grid, dim3(256), 0, stream, T, n, ldt, (int)wv, rm, n_map, anchor, n_out,
                        (int)k, out_rows, n_dst, out, ldo, err_flag);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
@@ -144,11 +145,12 @@ extern "C" int disco_gather_rows_f32(const float* x, int64_t ldx, int64_t width,
   const int vw = aligned(4) ? 4 : aligned(2) ? 2 : 1;
   const int64_t wv = width / vw;
   const int64_t blocks = (n_idx * wv + 255) / 256;
-  if (blocks > 0x7fffffffLL || wv > 0x3fffffff) return DISCO_EUNSUPPORTED;
+  if (wv > 0x3fffffff) return DISCO_EUNSUPPORTED;
+  DISCO_GRID(grid, blocks, 256);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (vw == 4) hipLaunchKernelGGL(k_gather_rows<float4>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, (int)wv, idx, n_idx, out, ldo);
-  else if (vw == 2) hipLaunchKernelGGL(k_gather_rows<float2>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, (int)wv, idx, n_idx, out, ldo);
-  else hipLaunchKernelGGL(k_gather_rows<float>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, (int)wv, idx, n_idx, out, ldo);
+  if (vw == 4) hipLaunchKernelGGL(k_gather_rows<float4>, grid, dim3(256), 0, stream, x, ldx, (int)wv, idx, n_idx, out, ldo);
+  else if (vw == 2) hipLaunchKernelGGL(k_gather_rows<float2>, grid, dim3(256), 0, stream, x, ldx, (int)wv, idx, n_idx, out, ldo);
+  else hipLaunchKernelGGL(k_gather_rows<float>, grid, dim3(256), 0, stream, x, ldx, (int)wv, idx, n_idx, out, ldo);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
 }
@@ -168,15 +170,16 @@ extern "C" int disco_pair_gather_f32(const float* Z, int64_t n, int64_t ldz, int
   int64_t wv = width / vw;
   int64_t total = n_pairs * 2 * wv;
   int64_t blocks = (total + 255) / 256;
-  if (blocks > 0x7fffffffLL || wv > 0x3fffffff) return DISCO_EUNSUPPORTED;
+  if (wv > 0x3fffffff) return DISCO_EUNSUPPORTED;
+  DISCO_GRID(grid, blocks, 256);
   if (vw == 4)
-    hipLaunchKernelGGL(k_pair_gather<float4>, dim3((unsigned)blocks), dim3(256), 0, stream, Z, n, ldz, (int)wv, sel, src, dst,
+    hipLaunchKernelGGL(k_pair_gather<float4>, grid, dim3(256), 0, stream, Z, n, ldz, (int)wv, sel, src, dst,
                        n_edges, n_pairs, out, ldo, err_flag);
   else if (vw == 2)
-    hipLaunchKernelGGL(k_pair_gather<float2>, dim3((unsigned)blocks), dim3(256), 0, stream, Z, n, ldz, (int)wv, sel, src, dst,
+    hipLaunchKernelGGL(k_pair_gather<float2>, grid, dim3(256), 0, stream, Z, n, ldz, (int)wv, sel, src, dst,
                        n_edges, n_pairs, out, ldo, err_flag);
   else
-    hipLaunchKernelGGL(k_pair_gather<float>, dim3((unsigned)blocks), dim3(256), 0, stream, Z, n, ldz, (int)wv, sel, src, dst,
+    hipLaunchKernelGGL(k_pair_gather<float>, grid, dim3(256), 0, stream, Z, n, ldz, (int)wv, sel, src, dst,
                        n_edges, n_pairs, out, ldo, err_flag);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;

@@ -38,6 +38,42 @@ struct StreamArgs {
 };
 int launch_stream(const StreamArgs& a);   // DISCO_EUNSUPPORTED: shape outside the kernel, caller falls back
 
+// ---- launch shapes ---------------------------------------------------------------------------------------------
+// A dispatch carries its size per dimension as a 32-bit count of WORK-ITEMS: a 1-D launch of 2^32 or more work-items
+// (17 M workgroups of 256) does not fail, it silently runs `count mod 2^32` of them (measured on MI355X / ROCm 7.2,
+// tools/r3/gridlimit: 28 M workgroups asked for, 11.2 M ran, hipSuccess everywhere).  A 2-D grid whose dimensions
+// each stay below the limit runs in full.  grid_for() therefore cuts a workgroup count into (x, y) with at most 2^30
+// work-items along x (x a multiple of 8 when y > 1, so that `id % 8` keeps naming the XCD of a round-robin dispatch);
+// kernels launched this way read their linear workgroup id with block_id() and return for ids >= their count
+// (x * y may exceed it).  Kernels that keep using blockIdx.x alone are launched through grid_1d(), which refuses
+// (DISCO_EUNSUPPORTED) what would wrap.
+inline bool grid_for(int64_t blocks, int threads, dim3* g) {
+  if (blocks < 0 || threads <= 0) return false;
+  if (blocks == 0) blocks = 1;
+  const int64_t max_x = ((int64_t)1 << 30) / threads;
+  if (blocks <= max_x) { *g = dim3((unsigned)blocks, 1, 1); return true; }
+  const int64_t by = (blocks + max_x - 1) / max_x;
+  int64_t bx = (blocks + by - 1) / by;
+  bx = (bx + 7) / 8 * 8;
+  if (by > 65535) return false;
+  *g = dim3((unsigned)bx, (unsigned)by, 1);
+  return true;
+}
+inline bool grid_1d(int64_t blocks, int threads, dim3* g) {
+  if (blocks < 0 || threads <= 0 || (uint64_t)(blocks > 0 ? blocks : 1) * (uint64_t)threads >= ((uint64_t)1 << 32)) return false;
+  *g = dim3((unsigned)(blocks > 0 ? blocks : 1), 1, 1);
+  return true;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ int64_t block_id() { return (int64_t)blockIdx.y * gridDim.x + blockIdx.x; }
+#endif
+#define DISCO_GRID(g, blocks, threads) \
+  dim3 g;                              \
+  if (!::disco::grid_for((blocks), (threads), &g)) return DISCO_EUNSUPPORTED
+#define DISCO_GRID_1D(g, blocks, threads) \
+  dim3 g;                                 \
+  if (!::disco::grid_1d((blocks), (threads), &g)) return DISCO_EUNSUPPORTED
+
 #define DISCO_HIP_TRY(expr)                                    \
   do {                                                         \
     hipError_t e__ = (expr);                                   \

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_lpa_step(const int64_t* __restrict__ ro
   __shared__ uint32_t keys[4][kLpaSlots];
   __shared__ uint32_t cnts[4][kLpaSlots];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t v = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t v = block_id() * 4 + wave;
   if (v >= n) return;
   const uint32_t own = in[v];
   const int64_t b = rowptr[v], e = rowptr[v + 1];
@@ -99,12 +99,12 @@ __global__ __launch_bounds__(256) void k_lpa_step(const int64_t* __restrict__ ro
 }
 
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t* __restrict__ p, int64_t n, uint32_t value) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = block_id() * 256 + threadIdx.x;
   if (i < n) p[i] = value;
 }
 
 __global__ __launch_bounds__(256) void k_iota_u32(uint32_t* __restrict__ p, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = block_id() * 256 + threadIdx.x;
   if (i < n) p[i] = (uint32_t)i;
 }
 
@@ -125,22 +125,22 @@ extern "C" int disco_locality_labels(const int64_t* rowptr, const int32_t* col, 
   uint32_t* a = labels;
   uint32_t* b = static_cast<uint32_t*>(ws);
   uint32_t* size = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + (((size_t)n_rows * 4 + 255) & ~(size_t)255));
-  const unsigned fill_blocks = (unsigned)((n_rows + 255) / 256);
-  hipLaunchKernelGGL(k_iota_u32, dim3(fill_blocks), dim3(256), 0, s, a, n_rows);
+  DISCO_GRID(fill_grid, (n_rows + 255) / 256, 256);
+  hipLaunchKernelGGL(k_iota_u32, fill_grid, dim3(256), 0, s, a, n_rows);
   DISCO_CHECK_LAUNCH();
   const bool capped = max_group > 0;
   const uint32_t cap = (uint32_t)(max_group > 0xffffffffLL ? 0xffffffffLL : max_group);
   if (capped) {
-    hipLaunchKernelGGL(k_fill_u32, dim3(fill_blocks), dim3(256), 0, s, size, n_rows, 1u);   // every row alone in its group
+    hipLaunchKernelGGL(k_fill_u32, fill_grid, dim3(256), 0, s, size, n_rows, 1u);   // every row alone in its group
     DISCO_CHECK_LAUNCH();
   }
   const int64_t blocks = (n_rows + 3) / 4;
-  if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
+  DISCO_GRID(step_grid, blocks, 256);      // one wave per row: 64 work-items per row, 2^32 of them at 67 M rows
   for (int h = 0; h < 2 * sweeps; ++h) {        // two half-steps per sweep: an even number, the result ends up in `labels`
     if (capped)
-      hipLaunchKernelGGL(k_lpa_step<true>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, n_rows, (const uint32_t*)a, b, h & 1, size, cap);
+      hipLaunchKernelGGL(k_lpa_step<true>, step_grid, dim3(256), 0, s, rowptr, col, n_rows, (const uint32_t*)a, b, h & 1, size, cap);
     else
-      hipLaunchKernelGGL(k_lpa_step<false>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, n_rows, (const uint32_t*)a, b, h & 1, size, cap);
+      hipLaunchKernelGGL(k_lpa_step<false>, step_grid, dim3(256), 0, s, rowptr, col, n_rows, (const uint32_t*)a, b, h & 1, size, cap);
     DISCO_CHECK_LAUNCH();
     uint32_t* t = a; a = b; b = t;
   }

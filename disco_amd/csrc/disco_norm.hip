@@ -27,7 +27,7 @@ constexpr long long kLongMarker = 0x7ff8d15c0d15c000LL;   // a quiet NaN payload
 __global__ __launch_bounds__(256) void k_csr_rowsum(const int64_t* __restrict__ rowptr, const float* __restrict__ val,
                                                     int64_t n_rows, int add_identity, double* __restrict__ out) {
   const int gl = threadIdx.x & 15;
-  int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  int64_t row = (block_id() * 256 + threadIdx.x) >> 4;
   int64_t b = 0, e = 0;
   if (row < n_rows) { b = rowptr[row]; e = rowptr[row + 1]; }
   if (!add_identity) {
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(1024) void k_csr_rowsum_long(const int64_t* __restr
   __shared__ double part[1024];
   __shared__ int marked[1024];
   const int t = threadIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.x * 1024;
+  const int64_t r0 = block_id() * 1024;
   const int64_t mine = r0 + t;
   marked[t] = mine < n_rows && __double_as_longlong(out[mine]) == kLongMarker;
   __syncthreads();
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(1024) void k_csr_rowsum_long(const int64_t* __restr
 }
 
 __global__ __launch_bounds__(256) void k_inv_sqrt_norm(double* __restrict__ d, int64_t n, int add_identity) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t i = block_id() * 256 + threadIdx.x;
   if (i >= n) return;
   // np.power(rowsum, -1/2); inf -> 0 (utils.py:428-429).  In the float32 case the result is rounded to
   // float32 (numpy's own float32 pow is only accurate to a few ulp and differs between CPUs).
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_gcn_scale_csr(const int64_t* __restrict
                                                        const float* __restrict__ vin, int64_t n_rows, int64_t nnz,
                                                        int add_identity, const double* __restrict__ r,
                                                        float* __restrict__ vout) {
-  const int64_t c0 = (int64_t)blockIdx.x * kScaleChunk;
+  const int64_t c0 = block_id() * kScaleChunk;
   const int64_t c1 = c0 + kScaleChunk < nnz ? c0 + kScaleChunk : nnz;
   if (c0 >= c1) return;
   const int64_t r_lo = row_of_entry(rowptr, 0, n_rows - 1, c0);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_degree_count(const int64_t* __restrict_
   __shared__ unsigned int vals[kDegSlots];
   for (int h = threadIdx.x; h < kDegSlots; h += 256) { keys[h] = -1; vals[h] = 0u; }
   __syncthreads();
-  const int64_t c0 = (int64_t)blockIdx.x * kDegChunk;
+  const int64_t c0 = block_id() * kDegChunk;
   const int64_t c1 = c0 + kDegChunk < E ? c0 + kDegChunk : E;
   for (int64_t i = c0 + threadIdx.x; i < c1; i += 256) {
     const long long k = idx[i];
@@ -167,13 +167,13 @@ __global__ __launch_bounds__(256) void k_degree_count(const int64_t* __restrict_
 }
 
 __global__ __launch_bounds__(256) void k_u32_to_f32(float* __restrict__ d, int64_t n) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t i = block_id() * 256 + threadIdx.x;
   if (i < n) d[i] = (float)__float_as_uint(d[i]);
 }
 
 __global__ __launch_bounds__(256) void k_degree_ordered(const int64_t* __restrict__ segptr, const int64_t* __restrict__ order,
                                                         const float* __restrict__ w, int64_t N, float* __restrict__ deg) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t i = block_id() * 256 + threadIdx.x;
   if (i >= N) return;
   float s = 0.0f;
   for (int64_t k = segptr[i]; k < segptr[i + 1]; ++k) s += w[order[k]];  // serial float32, edge order
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_degree_ordered(const int64_t* __restric
 }
 
 __global__ __launch_bounds__(256) void k_inv_sqrt_f32(float* __restrict__ d, int64_t n) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t i = block_id() * 256 + threadIdx.x;
   if (i >= n) return;
   float r = 1.0f / sqrtf(d[i]);  // two correctly rounded ops == torch CPU pow_(-0.5)
   if (isinf(r)) r = 0.0f;
@@ -191,13 +191,13 @@ __global__ __launch_bounds__(256) void k_inv_sqrt_f32(float* __restrict__ d, int
 __global__ __launch_bounds__(256) void k_gcn_coo_apply(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
                                                        const float* __restrict__ w, int64_t E, const float* __restrict__ dis,
                                                        float* __restrict__ out) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t i = block_id() * 256 + threadIdx.x;
   if (i >= E) return;
   float wi = w ? w[i] : 1.0f;
   out[i] = __fmul_rn(__fmul_rn(dis[row[i]], wi), dis[col[i]]);
 }
 
-static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+static inline int64_t blocks_for(int64_t n, int per) { return (n + per - 1) / per; }
 
 }  // namespace disco
 
@@ -245,10 +245,12 @@ extern "C" int disco_csr_rowsum_f64(const int64_t* rowptr, const float* val, int
   if (n_rows < 0) return DISCO_EINVAL;
   if (n_rows == 0) return DISCO_OK;
   if (!rowptr || !rowsum) return DISCO_EINVAL;
-  hipLaunchKernelGGL(k_csr_rowsum, dim3(blocks_for(n_rows, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), rowptr,
+  DISCO_GRID(g_rows, blocks_for(n_rows, 16), 256);
+  DISCO_GRID(g_long, blocks_for(n_rows, 1024), 1024);
+  hipLaunchKernelGGL(k_csr_rowsum, g_rows, dim3(256), 0, static_cast<hipStream_t>(stream), rowptr,
                      val, n_rows, add_identity, rowsum);
   if (add_identity && val)
-    hipLaunchKernelGGL(k_csr_rowsum_long, dim3(blocks_for(n_rows, 1024)), dim3(1024), 0, static_cast<hipStream_t>(stream), rowptr,
+    hipLaunchKernelGGL(k_csr_rowsum_long, g_long, dim3(1024), 0, static_cast<hipStream_t>(stream), rowptr,
                        val, n_rows, rowsum);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
@@ -260,13 +262,15 @@ extern "C" int disco_gcn_norm_csr_f32(const int64_t* rowptr, const int32_t* col,
   if (n_rows == 0) return DISCO_OK;
   if (!rowptr || !col || !rowsum || !val_out) return DISCO_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(k_inv_sqrt_norm, dim3(blocks_for(n_rows, 256)), dim3(256), 0, s, rowsum, n_rows, add_identity);
+  DISCO_GRID(g_n, blocks_for(n_rows, 256), 256);
+  hipLaunchKernelGGL(k_inv_sqrt_norm, g_n, dim3(256), 0, s, rowsum, n_rows, add_identity);
   int64_t nnz = 0;   // rowptr lives on the device: the entry count is its last element
   DISCO_HIP_TRY(hipMemcpyAsync(&nnz, rowptr + n_rows, sizeof(nnz), hipMemcpyDeviceToHost, s));
   DISCO_HIP_TRY(hipStreamSynchronize(s));
   if (nnz < 0 || (nnz + kScaleChunk - 1) / kScaleChunk > 0x7fffffffLL) return DISCO_EINVAL;
+  DISCO_GRID(g_nnz, blocks_for(nnz, kScaleChunk), 256);
   if (nnz > 0)
-    hipLaunchKernelGGL(k_gcn_scale_csr, dim3((unsigned)((nnz + kScaleChunk - 1) / kScaleChunk)), dim3(256), 0, s, rowptr, col,
+    hipLaunchKernelGGL(k_gcn_scale_csr, g_nnz, dim3(256), 0, s, rowptr, col,
                        val_in, n_rows, nnz, add_identity, (const double*)rowsum, val_out);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
@@ -278,8 +282,10 @@ extern "C" int disco_degree_count_f32(const int64_t* idx, int64_t E, int64_t N, 
   if (!deg || (E > 0 && !idx)) return DISCO_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   DISCO_HIP_TRY(hipMemsetAsync(deg, 0, sizeof(float) * (size_t)N, s));
-  if (E > 0) hipLaunchKernelGGL(k_degree_count, dim3(blocks_for(E, kDegChunk)), dim3(256), 0, s, idx, E, N, reinterpret_cast<unsigned int*>(deg));
-  hipLaunchKernelGGL(k_u32_to_f32, dim3(blocks_for(N, 256)), dim3(256), 0, s, deg, N);
+  DISCO_GRID(g_e, blocks_for(E, kDegChunk), 256);
+  DISCO_GRID(g_n, blocks_for(N, 256), 256);
+  if (E > 0) hipLaunchKernelGGL(k_degree_count, g_e, dim3(256), 0, s, idx, E, N, reinterpret_cast<unsigned int*>(deg));
+  hipLaunchKernelGGL(k_u32_to_f32, g_n, dim3(256), 0, s, deg, N);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
 }
@@ -289,7 +295,8 @@ extern "C" int disco_degree_ordered_f32(const int64_t* segptr, const int64_t* or
   if (N < 0) return DISCO_EINVAL;
   if (N == 0) return DISCO_OK;
   if (!segptr || !order || !w || !deg) return DISCO_EINVAL;
-  hipLaunchKernelGGL(k_degree_ordered, dim3(blocks_for(N, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), segptr, order,
+  DISCO_GRID(g_n, blocks_for(N, 256), 256);
+  hipLaunchKernelGGL(k_degree_ordered, g_n, dim3(256), 0, static_cast<hipStream_t>(stream), segptr, order,
                      w, N, deg);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
@@ -299,7 +306,8 @@ extern "C" int disco_inv_sqrt_f32(float* deg, int64_t N, void* stream) {
   if (N < 0) return DISCO_EINVAL;
   if (N == 0) return DISCO_OK;
   if (!deg) return DISCO_EINVAL;
-  hipLaunchKernelGGL(k_inv_sqrt_f32, dim3(blocks_for(N, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), deg, N);
+  DISCO_GRID(g_n, blocks_for(N, 256), 256);
+  hipLaunchKernelGGL(k_inv_sqrt_f32, g_n, dim3(256), 0, static_cast<hipStream_t>(stream), deg, N);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
 }
@@ -309,7 +317,8 @@ extern "C" int disco_gcn_norm_coo_apply_f32(const int64_t* row, const int64_t* c
   if (E < 0) return DISCO_EINVAL;
   if (E == 0) return DISCO_OK;
   if (!row || !col || !dis || !w_out) return DISCO_EINVAL;
-  hipLaunchKernelGGL(k_gcn_coo_apply, dim3(blocks_for(E, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), row, col, w_in,
+  DISCO_GRID(g_e, blocks_for(E, 256), 256);
+  hipLaunchKernelGGL(k_gcn_coo_apply, g_e, dim3(256), 0, static_cast<hipStream_t>(stream), row, col, w_in,
                      E, dis, w_out);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;

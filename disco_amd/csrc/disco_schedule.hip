@@ -45,7 +45,7 @@ template <typename KEY>
 __global__ void k_row_keys(const int64_t* __restrict__ rowptr, int64_t n_rows, int64_t hub_threshold, int natural,
                            const uint32_t* __restrict__ row_group, KEY* __restrict__ keys, uint32_t* __restrict__ rows,
                            Counters* cnt) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t r = block_id() * blockDim.x + threadIdx.x;
   unsigned long long nnz = 0;
   bool hub = false;
   if (r < n_rows) {
@@ -82,7 +82,7 @@ __global__ void k_row_keys(const int64_t* __restrict__ rowptr, int64_t n_rows, i
 __global__ void k_hub_count(const int64_t* __restrict__ rowptr, const uint32_t* __restrict__ perm, const Counters* cnt,
                             int64_t hub_piece, int64_t n_max, int64_t* __restrict__ pieces, int64_t* __restrict__ slots,
                             int64_t* __restrict__ multi) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t i = block_id() * blockDim.x + threadIdx.x;
   if (i >= n_max) return;
   int64_t p = 0;
   if (i < (int64_t)cnt->n_hub) {
@@ -101,7 +101,7 @@ __global__ void k_hub_emit(const int64_t* __restrict__ rowptr, const uint32_t* _
                            int32_t* __restrict__ piece_row, int64_t* __restrict__ piece_begin,
                            int64_t* __restrict__ piece_end, int32_t* __restrict__ piece_slot,
                            int32_t* __restrict__ multi_row, int64_t* __restrict__ multi_first) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t i = block_id() * blockDim.x + threadIdx.x;
   int64_t n_hub = (int64_t)cnt->n_hub;
   if (i >= n_max || i >= n_hub) return;
   int64_t r = perm[i];
@@ -258,12 +258,12 @@ static int schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz, in
 
   DISCO_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(Counters), stream));
   {
-    int64_t blocks = (n_rows + 255) / 256;
+    DISCO_GRID(key_grid, (n_rows + 255) / 256, 256);
     size_t sort_tmp = L.sort_tmp;
     if (grouped) {
       uint64_t* keys_in = reinterpret_cast<uint64_t*>(ws + L.off_keys_in);
       uint64_t* keys_out = reinterpret_cast<uint64_t*>(ws + L.off_keys_out);
-      hipLaunchKernelGGL(k_row_keys<uint64_t>, dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, n_rows, T, natural,
+      hipLaunchKernelGGL(k_row_keys<uint64_t>, key_grid, dim3(256), 0, stream, rowptr, n_rows, T, natural,
                          row_group, keys_in, rows_in, cnt);
       DISCO_CHECK_LAUNCH();
       DISCO_HIP_TRY(rocprim::radix_sort_pairs(tmp, sort_tmp, (const uint64_t*)keys_in, keys_out, (const uint32_t*)rows_in,
@@ -271,7 +271,7 @@ static int schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz, in
     } else {
       uint8_t* keys_in = reinterpret_cast<uint8_t*>(ws + L.off_keys_in);
       uint8_t* keys_out = reinterpret_cast<uint8_t*>(ws + L.off_keys_out);
-      hipLaunchKernelGGL(k_row_keys<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, n_rows, T, natural,
+      hipLaunchKernelGGL(k_row_keys<uint8_t>, key_grid, dim3(256), 0, stream, rowptr, n_rows, T, natural,
                          (const uint32_t*)nullptr, keys_in, rows_in, cnt);
       DISCO_CHECK_LAUNCH();
       DISCO_HIP_TRY(rocprim::radix_sort_pairs(tmp, sort_tmp, (const uint8_t*)keys_in, keys_out, (const uint32_t*)rows_in,
@@ -283,9 +283,9 @@ static int schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz, in
     int64_t* a = reinterpret_cast<int64_t*>(ws + L.off_scan_a);
     int64_t* b = reinterpret_cast<int64_t*>(ws + L.off_scan_b);
     int64_t* c = reinterpret_cast<int64_t*>(ws + L.off_scan_c);
-    int64_t blocks = (L.n_hub_max + 255) / 256;
+    DISCO_GRID(hub_grid, (L.n_hub_max + 255) / 256, 256);
     // slots/multi are produced into b/c then scanned in place after pieces -> a
-    hipLaunchKernelGGL(k_hub_count, dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, perm, cnt, P, L.n_hub_max, pieces,
+    hipLaunchKernelGGL(k_hub_count, hub_grid, dim3(256), 0, stream, rowptr, perm, cnt, P, L.n_hub_max, pieces,
                        b, c);
     DISCO_CHECK_LAUNCH();
     size_t scan_tmp = L.scan_tmp;
@@ -299,7 +299,7 @@ static int schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz, in
     scan_tmp = L.scan_tmp;
     DISCO_HIP_TRY(rocprim::exclusive_scan(tmp, scan_tmp, (const int64_t*)c, b, (int64_t)0, (size_t)L.n_hub_max,
                                           rocprim::plus<int64_t>(), stream));
-    hipLaunchKernelGGL(k_hub_emit, dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, perm, cnt, P, L.n_hub_max,
+    hipLaunchKernelGGL(k_hub_emit, hub_grid, dim3(256), 0, stream, rowptr, perm, cnt, P, L.n_hub_max,
                        (const int64_t*)a, (const int64_t*)pieces, (const int64_t*)b,
                        reinterpret_cast<int32_t*>(ws + L.off_piece_row), reinterpret_cast<int64_t*>(ws + L.off_piece_begin),
                        reinterpret_cast<int64_t*>(ws + L.off_piece_end), reinterpret_cast<int32_t*>(ws + L.off_piece_slot),

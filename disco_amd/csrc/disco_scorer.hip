@@ -614,7 +614,8 @@ extern "C" int disco_sym_threshold_count(const float* S, int64_t n, int64_t lds,
   if (n < 0 || variant < 0 || variant > 2) return DISCO_EINVAL;
   if (n == 0) return DISCO_OK;
   if (!S || !rowcount || lds < n) return DISCO_EINVAL;
-  hipLaunchKernelGGL(k_sym_count, dim3((unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream_), S, n, lds, threshold, variant,
+  DISCO_GRID_1D(g_cnt, n, 256);
+  hipLaunchKernelGGL(k_sym_count, g_cnt, dim3(256), 0, static_cast<hipStream_t>(stream_), S, n, lds, threshold, variant,
                      rowcount);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;
@@ -625,7 +626,8 @@ extern "C" int disco_sym_threshold_fill(const float* S, int64_t n, int64_t lds, 
   if (n < 0 || E < 0 || variant < 0 || variant > 2) return DISCO_EINVAL;
   if (n == 0 || E == 0) return DISCO_OK;
   if (!S || !rowstart || !edge_index || !edge_weight || lds < n) return DISCO_EINVAL;
-  hipLaunchKernelGGL(k_sym_fill, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream_), S, n, lds, threshold, variant,
+  DISCO_GRID_1D(g_fill, n, 64);
+  hipLaunchKernelGGL(k_sym_fill, g_fill, dim3(64), 0, static_cast<hipStream_t>(stream_), S, n, lds, threshold, variant,
                      rowstart, E, edge_index, edge_weight);
   DISCO_CHECK_LAUNCH();
   return DISCO_OK;

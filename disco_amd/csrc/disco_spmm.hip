@@ -111,10 +111,11 @@ __global__ __launch_bounds__(256) void k_spmm_rows(const int64_t* __restrict__ r
   // b + 8 share an L2.  With xcd_chunk > 0 the row order is cut into runs of xcd_chunk blocks and the runs are dealt
   // to the XCDs in turn: the workgroups of one XCD walk a run of CONSECUTIVE rows (rows of a locality-grouped order
   // share neighbours: their gathers hit that XCD's L2) while all eight stay in the same region of the order.
-  int64_t bid = blockIdx.x;
+  // linear workgroup id: the launch is 2-D once rows x G reaches 2^32 work-items (disco_internal.h, grid_for)
+  int64_t bid = block_id();
   if (xcd_chunk > 0) {
-    const uint32_t q = blockIdx.x >> 3, c = (uint32_t)xcd_chunk;
-    bid = ((int64_t)(q / c) * 8 + (blockIdx.x & 7)) * c + q % c;
+    const uint32_t lb = (uint32_t)bid, q = lb >> 3, c = (uint32_t)xcd_chunk;
+    bid = ((int64_t)(q / c) * 8 + (lb & 7)) * c + q % c;
   }
   int64_t grp = (bid * 4 + wave) * RPW + lane / G;
   if (grp >= count) return;
@@ -662,14 +663,16 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
     count = s.n_rows - s.n_hub_rows;
     if (s.n_hub_pieces > 0) {
       size_t lds_bytes = (size_t)(512 / G) * nvec * VEC * sizeof(float);
-      hipLaunchKernelGGL((k_spmm_hub<VEC, G, NV, OP, HASVAL, A24>), dim3((unsigned)s.n_hub_pieces), dim3(512), lds_bytes, a.stream,
+      DISCO_GRID_1D(hub_grid, s.n_hub_pieces, 512);
+      DISCO_GRID_1D(multi_grid, s.n_multi_rows, 256);
+      hipLaunchKernelGGL((k_spmm_hub<VEC, G, NV, OP, HASVAL, A24>), hub_grid, dim3(512), lds_bytes, a.stream,
                          a.rowptr, a.col, a.val, a.x, a.ldx, a.y, a.ldy, nvec,
                          reinterpret_cast<const int32_t*>(a.sched + s.off_piece_row),
                          reinterpret_cast<const int64_t*>(a.sched + s.off_piece_begin),
                          reinterpret_cast<const int64_t*>(a.sched + s.off_piece_end),
                          reinterpret_cast<const int32_t*>(a.sched + s.off_piece_slot), a.partial, a.ldp, mean, (int)a.F);
       if (s.n_multi_rows > 0) {
-        hipLaunchKernelGGL((k_hub_combine<OP>), dim3((unsigned)s.n_multi_rows), dim3(256), 0, a.stream, a.rowptr,
+        hipLaunchKernelGGL((k_hub_combine<OP>), multi_grid, dim3(256), 0, a.stream, a.rowptr,
                            reinterpret_cast<const int32_t*>(a.sched + s.off_multi_row),
                            reinterpret_cast<const int64_t*>(a.sched + s.off_multi_first), a.partial, a.ldp, a.y, a.ldy,
                            a.F, mean);
@@ -720,14 +723,17 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
   }
   if constexpr ((VEC == 4 || VEC == 2) && G >= 16) {
     // windowed launches (L2-blocked): mean of an accumulating call is not meaningful, so SUM_ACC + MEAN never meet
-    if (!swept && count > 0 && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && tuning().sweep_mode >= 2) {
+    int win_rpg = tuning().win_rows_per_group > 0 ? tuning().win_rows_per_group : DISCO_WIN_MAXR;
+    if (win_rpg > DISCO_WIN_MAXR) win_rpg = DISCO_WIN_MAXR;
+    // the windowed kernel indexes with blockIdx.x alone: a row count whose 1-D launch would wrap takes the plain kernel
+    dim3 win_grid;
+    const bool win_fits = grid_1d(((count + 4 * RPW * win_rpg - 1) / (4 * RPW * win_rpg) + 7) / 8 * 8, 256, &win_grid);
+    if (!swept && win_fits && count > 0 && a.info && a.info->sweep_ws && a.info->sweep_windows > 0 && tuning().sweep_mode >= 2) {
       const disco_schedule_info& s = *a.info;
       const uint32_t* wptr = reinterpret_cast<const uint32_t*>(s.sweep_ws);
       const int P = (int)s.sweep_windows;
-      int rpg = tuning().win_rows_per_group > 0 ? tuning().win_rows_per_group : DISCO_WIN_MAXR;
-      if (rpg > DISCO_WIN_MAXR) rpg = DISCO_WIN_MAXR;
+      const int rpg = win_rpg;
       int64_t blocks = (count + 4 * RPW * rpg - 1) / (4 * RPW * rpg);
-      if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
       // the variant without a masked tail stores through a buffer descriptor on y (32-bit offsets, `sc1`): a y block of
       // 4 GiB or more takes the other variant, whose stores are plain and whose tail count may be 0
       const bool tail = (a.F % VEC) != 0 || (uint64_t)s.n_rows * (uint64_t)a.ldy * 4u >= (1ull << 32);
@@ -781,7 +787,8 @@ static int launch_cfg(const SpmmArgs& a, int nvec) {
       blocks = (blocks + 8 * xcd_chunk - 1) / (8 * xcd_chunk) * (8 * xcd_chunk);
     }
     if (blocks > 0x7fffffffLL) return DISCO_EUNSUPPORTED;
-    hipLaunchKernelGGL((k_spmm_rows<VEC, G, NV, OP, HASVAL, A24>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.rowptr, a.col,
+    DISCO_GRID(row_grid, blocks, 256);        // 2-D beyond 2^30 work-items: a 1-D launch of 2^32 wraps around silently
+    hipLaunchKernelGGL((k_spmm_rows<VEC, G, NV, OP, HASVAL, A24>), row_grid, dim3(256), 0, a.stream, a.rowptr, a.col,
                        a.val, a.x, a.ldx, a.y, a.ldy, nvec, perm, first, count, mean, (int)a.F, xcd_chunk);
   }
   hipError_t e = hipGetLastError();

@@ -209,3 +209,70 @@ def test_products_shaped_row_partitioned_at_full_size(tmp_path):
         assert got[exchange].shape == (n_sample, F)
         assert_fwd_close(got[exchange], y64, K * bound, what=f"products row-partitioned, exchange={exchange}")
     assert np.array_equal(got["need"], got["dense"]), "interior first, halo second: the exchange mode does not change a bit"
+
+
+def test_launches_beyond_two_to_the_32_work_items():
+    """A 1-D dispatch carries its size as a 32-bit count of work-items; 2^32 or more do not fail, they wrap around and only
+    `count mod 2^32` run (measured: tools/r3/gridlimit).  The row kernel spends G lanes per row and the locality pass a wave
+    per row, so 67 M rows of a table wider than 128 floats are past that point (the papers100M-shaped graph has 111 M).
+    70 M rows, one entry each, F = 132 (G = 64): every row of A x, with and without a schedule, against plain indexing;
+    the label pass against its torch restatement; the entry-parallel weight kernel at 2^32 + 2^18 edges through the C ABI."""
+    from disco_amd import SparseTensor, _lib, ops
+    dev = torch.device(DEV)
+    n, F = 70_000_000, 132
+    _progress(f"[wrap] building n={n} F={F}")
+    ids = torch.arange(n, device=dev)
+    col = (ids * 48_271 + 12_345) % n
+    rowptr = torch.arange(n + 1, device=dev)
+    val = ((ids % 7) + 1).to(torch.float32)
+    adj = SparseTensor(rowptr=rowptr, col=col, value=val, sparse_sizes=(n, n), is_sorted=True)
+    x = torch.empty((n, F), dtype=torch.float32, device=dev)
+    chunk = 1 << 22
+    for i in range(0, n, chunk):
+        r = ids[i:i + chunk]
+        x[i:i + chunk] = (r % 1013).to(torch.float32)[:, None] + torch.arange(F, device=dev, dtype=torch.float32)[None, :] * 0.5
+    for use_schedule in (False, True):
+        y = torch.full((n, F), float("nan"), dtype=torch.float32, device=dev)
+        ops.spmm_raw(adj, x, "sum", out=y, use_schedule=use_schedule)
+        torch.cuda.synchronize()
+        _progress(f"[wrap] spmm schedule={use_schedule} done, checking")
+        bad = 0
+        for i in range(0, n, chunk):
+            ref = x[col[i:i + chunk]] * val[i:i + chunk, None]
+            bad += int((y[i:i + chunk] != ref).any(dim=1).sum())
+        assert bad == 0, f"schedule={use_schedule}: {bad} rows of {n} wrong or never written"
+        del y
+    del x
+    _progress("[wrap] locality pass")
+    labels = adj.locality_groups(sweeps=1, max_group=0)
+
+    def half_step(lab, parity):
+        # votes: the row's own label and its only neighbour's, one each -> the smaller hash wins (tests/test_gpu_locality.py)
+        nb = lab[col]
+        pick = torch.where((nb * 2654435761) % (1 << 32) < (lab * 2654435761) % (1 << 32), nb, lab)
+        return torch.where(((ids + parity) & 1) == 0, pick, lab)
+
+    a2 = half_step(half_step(ids, 0), 1)
+    assert torch.equal(labels.long(), a2)
+    del labels, a2, adj, col, rowptr, val
+    torch.cuda.empty_cache()
+    _progress("[wrap] weight kernel at 2^32 + 2^18 edges")
+    E, m = (1 << 32) + (1 << 18), 1_000_003
+    lib = _lib.load()
+    dis = (torch.arange(m, device=dev) % 97 + 1).to(torch.float32)
+    row = torch.empty(E, dtype=torch.int64, device=dev)
+    colE = torch.empty(E, dtype=torch.int64, device=dev)
+    big = 1 << 26
+    for i in range(0, E, big):
+        e = torch.arange(i, min(i + big, E), device=dev)
+        row[i:i + big] = e % m
+        colE[i:i + big] = (e * 7 + 3) % m
+    out = torch.full((E,), float("nan"), dtype=torch.float32, device=dev)
+    _lib.check(lib.disco_gcn_norm_coo_apply_f32(_lib.ptr(row), _lib.ptr(colE), None, E, _lib.ptr(dis), _lib.ptr(out), _lib.current_stream(dev)),
+               "disco_gcn_norm_coo_apply_f32")
+    torch.cuda.synchronize()
+    bad = 0
+    for i in range(0, E, big):
+        bad += int((out[i:i + big] != dis[row[i:i + big]] * dis[colE[i:i + big]]).sum())
+    assert bad == 0, f"{bad} of {E} weights wrong or never written"
+    _progress("[wrap] done")
