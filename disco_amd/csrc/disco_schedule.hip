@@ -230,7 +230,8 @@ static int schedule_build(const int64_t* rowptr, int64_t n_rows, int64_t nnz, in
                           const uint32_t* row_group, void* sched_ws, size_t sched_ws_bytes, disco_schedule_info* info,
                           void* stream_) {
   const bool grouped = row_group != nullptr;
-  if (!info || n_rows < 0 || nnz < 0 || n_rows > 0xffffffffLL) return DISCO_EINVAL;
+  if (!info || n_rows < 0 || nnz < 0) return DISCO_EINVAL;
+  if (n_rows > 0x7fffffffLL) return DISCO_EUNSUPPORTED;     // piece_row / multi_row are int32, perm uint32
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   int natural = 0;
   if (hub_threshold < 0) { natural = 1; hub_threshold = -hub_threshold; }  // negative threshold: keep natural row order
