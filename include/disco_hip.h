@@ -14,7 +14,11 @@
  *     whose size they query first;
  *   - return value: 0 = ok, <0 = error (see disco_status_string); no exceptions cross the ABI;
  *   - CSR: rowptr int64[n_rows+1], col int32[nnz], val float32[nnz] (val may be NULL = all 1);
- *   - dense operands are row-major float32 with an explicit leading dimension in elements.
+ *   - dense operands are row-major float32 with an explicit leading dimension in elements;
+ *   - sizes: every count is int64.  Launches whose size grows with rows, entries or edges are shaped so that no
+ *     dimension reaches 2^32 work-items (a 1-D launch of that size would silently run only part of its workgroups
+ *     on this stack); what cannot be shaped that way is refused with DISCO_EUNSUPPORTED, never truncated.  Hard
+ *     limits: col is int32 (n_cols < 2^31), schedules take at most 2^31-1 rows, a window table needs nnz < 2^32.
  */
 #ifndef DISCO_HIP_H
 #define DISCO_HIP_H
