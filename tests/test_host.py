@@ -287,3 +287,46 @@ def test_truncated_head_generator_caps_the_expected_degree():
     assert bool((key[1:] > key[:-1]).all())                       # still unique and row-major sorted
     rt, ct, offs = graphgen.partition_edges(n, nnz, 0.9, 3, world=2, rank=1, max_degree=600)
     assert int(torch.bincount(rt).max()) < 1.25 * 600
+
+
+def test_grid_helpers_never_hand_out_a_dimension_that_wraps(tmp_path):
+    """disco_internal.h: grid_for() must cover every workgroup with each dimension below 2^32 work-items (a 1-D launch of
+    2^32 work-items silently runs only part of them, profiles/r3/r3_gridlimit.log), keep x a multiple of 8 once it is 2-D,
+    and grid_1d() must refuse exactly what would wrap.  Host-only program, compiled here with hipcc (no GPU needed)."""
+    import shutil
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("hipcc not found")
+    src = tmp_path / "grids.hip"
+    src.write_text('''
+#include "disco_internal.h"
+#include <cstdio>
+int main() {
+  const int64_t cases[] = {0, 1, 7, 4194304, 4194305, 16777215, 16777216, 17000000, 27764989, 100000000, 2147483647LL,
+                           274877906944LL, 70368744177664LL};
+  for (int threads : {64, 256, 512, 1024}) for (int64_t b : cases) {
+    dim3 g, h;
+    const bool ok = disco::grid_for(b, threads, &g), ok1 = disco::grid_1d(b, threads, &h);
+    printf("%d %lld %d %u %u %d %u\\n", threads, (long long)b, (int)ok, ok ? g.x : 0u, ok ? g.y : 0u, (int)ok1, ok1 ? h.x : 0u);
+  }
+  return 0;
+}
+''')
+    exe = tmp_path / "grids"
+    subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-w", f"-I{os.path.join(ROOT, 'disco_amd', 'csrc')}", "-o", str(exe), str(src)],
+                   check=True, capture_output=True, timeout=300)
+    lines = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=60).stdout.split("\n")
+    seen = 0
+    for ln in filter(None, lines):
+        threads, b, ok, x, y, ok1, x1 = (int(v) for v in ln.split())
+        need = max(b, 1)
+        if ok:
+            assert x * y >= need and x * threads <= 1 << 30 and 1 <= y <= 65535, ln
+            assert (x - 1) * y < need + 8 * y, ln                        # no more than the rounding of x to a multiple of 8 is idle
+            assert y == 1 or x % 8 == 0, ln
+        else:
+            assert need > (((1 << 30) // threads) // 8 * 8) * 65535, ln    # refused only when 65535 rows of blocks cannot hold it
+        assert bool(ok1) == (need * threads < 1 << 32), ln
+        assert not ok1 or x1 == need
+        seen += 1
+    assert seen == 4 * 13
