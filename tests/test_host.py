@@ -330,3 +330,93 @@ int main() {
         assert not ok1 or x1 == need
         seen += 1
     assert seen == 4 * 13
+
+
+def test_partition_helpers_cover_their_range_exactly():
+    """Property sweep (hypothesis) of the pure partition helpers of disco_amd.dist / graphgen / sparse: every cut list
+    starts at 0, ends at the size, never decreases; slabs and chunks respect their alignment; the nnz-balanced row cuts
+    never give a rank more than its share plus one row's entries."""
+    from hypothesis import given, settings, strategies as st
+    from disco_amd import dist as dd
+    from disco_amd.sparse import sweep_window_rows
+
+    @settings(max_examples=300, deadline=None)
+    @given(F=st.integers(1, 5000), world=st.integers(1, 64))
+    def slabs(F, world):
+        s = dd.feature_slabs(F, world)
+        assert len(s) == world and s[0][0] == 0 and s[-1][1] == F
+        for (a0, a1), (b0, b1) in zip(s, s[1:]):
+            assert a1 == b0
+        for c0, c1 in s:
+            assert 0 <= c0 <= c1 <= F and c0 % 4 == 0 and (c1 % 4 == 0 or c1 == F)
+        widths = [c1 - c0 for c0, c1 in s]
+        assert max(widths) - min(widths) <= 4 + 3                  # as equal as 4-float units allow (the last unit may be partial)
+
+    @settings(max_examples=300, deadline=None)
+    @given(F=st.integers(1, 5000))
+    def chunks(F):
+        c = dd.RowPartition._col_chunks(F)
+        assert c[0][0] == 0 and c[-1][1] == F and all(a[1] == b[0] for a, b in zip(c, c[1:]))
+        assert all(c0 % 32 == 0 and 0 < c1 - c0 <= 160 for c0, c1 in c)
+
+    @settings(max_examples=200, deadline=None)
+    @given(n=st.integers(0, 10 ** 9), world=st.integers(1, 64))
+    def blocks(n, world):
+        o = graphgen.block_offsets(n, world)
+        assert o[0] == 0 and o[-1] == n and all(a <= b for a, b in zip(o, o[1:])) and max(b - a for a, b in zip(o, o[1:])) - min(b - a for a, b in zip(o, o[1:])) <= 1
+
+    @settings(max_examples=200, deadline=None)
+    @given(deg=st.lists(st.integers(0, 50), min_size=0, max_size=200), world=st.integers(1, 9))
+    def balanced(deg, world):
+        rowptr = torch.zeros(len(deg) + 1, dtype=torch.int64)
+        if deg:
+            rowptr[1:] = torch.tensor(deg).cumsum(0)
+        o = dd.balanced_row_offsets(rowptr, world)
+        assert len(o) == world + 1 and o[0] == 0 and o[-1] == len(deg) and all(a <= b for a, b in zip(o, o[1:]))
+        nnz = int(rowptr[-1])
+        for g in range(world):
+            share = int(rowptr[o[g + 1]] - rowptr[o[g]])
+            assert share <= nnz // world + 1 + 2 * (max(deg) if deg else 0)
+
+    @settings(max_examples=200, deadline=None)
+    @given(F=st.integers(1, 4000), wb=st.integers(1 << 10, 1 << 26))
+    def window(F, wb):
+        r = sweep_window_rows(F, wb)
+        assert r >= 64
+        blk = min(128, (F + 31) // 32 * 32)
+        assert r == 64 or r * 4 * 32 <= wb                           # a window of the narrowest block fits the budget
+
+    slabs(); chunks(); blocks(); balanced(); window()
+
+
+def test_sparse_tensor_host_construction_properties():
+    """Property sweep of the host-side SparseTensor (the reference builds its adjacency from host tensors,
+    LargeScaleCondensing.py:486): row-major order, duplicates kept in input order (torch_sparse's constructor), transpose
+    stable in the original entry order, dense forms equal to scipy's."""
+    import scipy.sparse as sp
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=150, deadline=None)
+    @given(m=st.integers(1, 12), n=st.integers(1, 12), data=st.data())
+    def check(m, n, data):
+        e = data.draw(st.integers(0, 40))
+        row = np.array(data.draw(st.lists(st.integers(0, m - 1), min_size=e, max_size=e)), dtype=np.int64)
+        col = np.array(data.draw(st.lists(st.integers(0, n - 1), min_size=e, max_size=e)), dtype=np.int64)
+        val = np.arange(1, e + 1, dtype=np.float32)                 # distinct: the order of duplicates is visible
+        a = SparseTensor(row=torch.from_numpy(row), col=torch.from_numpy(col), value=torch.from_numpy(val), sparse_sizes=(m, n))
+        rp, c, v = a.csr()
+        assert rp.tolist() == np.concatenate([[0], np.cumsum(np.bincount(row, minlength=m))]).tolist()
+        order = np.lexsort((np.arange(e), col, row))                  # by row, then column, then input position
+        assert c.tolist() == col[order].tolist() and v.tolist() == val[order].tolist()
+        dense = sp.coo_matrix((val, (row, col)), shape=(m, n)).toarray()
+        assert np.array_equal(a.to_dense().numpy(), dense)
+        t = a.t()
+        assert t.sparse_sizes() == (n, m) and np.array_equal(t.to_dense().numpy(), dense.T)
+        rt, ct, vt = t.csr()
+        order_t = np.lexsort((np.arange(e), row[order], col[order]))  # stable in the CSR entry order
+        assert ct.tolist() == row[order][order_t].tolist() and vt.tolist() == val[order][order_t].tolist()
+        assert t.t() is a
+        r2, c2, v2 = a.coo()
+        assert r2.tolist() == row[order].tolist() and c2.tolist() == col[order].tolist()
+
+    check()
