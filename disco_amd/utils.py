@@ -64,6 +64,18 @@ def _require_cuda(t: torch.Tensor, what: str) -> None:
         raise RuntimeError(f"{what}: tensors must live on the GPU (got {t.device}); disco_amd has no CPU fallback")
 
 
+def _staging_device(t: torch.Tensor, what: str):
+    """The reference calls its normalisation functions on HOST tensors (LargeScaleCondensing.py:480,
+    LargeScaleCondensing_Sampled.py:491).  There is still no CPU arithmetic here: a host operand is copied to the
+    current GPU, the kernels run there, and the result goes back to the operand's device like the reference's does.
+    Returns the GPU to compute on, or None when the operand already lives on one."""
+    if t.device.type == "cuda":
+        return None
+    if not torch.cuda.is_available():
+        raise RuntimeError(f"{what}: no GPU is visible and disco_amd has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 def gcn_norm(edge_index: Union[torch.Tensor, SparseTensor], edge_weight: Optional[torch.Tensor] = None,
              num_nodes: Optional[int] = None, improved: bool = False, add_self_loops: bool = True,
              flow: str = "source_to_target", dtype=None):
@@ -104,7 +116,12 @@ def gcn_norm(edge_index: Union[torch.Tensor, SparseTensor], edge_weight: Optiona
         return adj_t.set_value(out)
 
     assert flow in ["source_to_target", "target_to_source"]
-    _require_cuda(edge_index, "gcn_norm")
+    stage = _staging_device(edge_index, "gcn_norm")
+    if stage is not None:
+        home = edge_index.device
+        ei, ew = gcn_norm(edge_index.to(stage), None if edge_weight is None else edge_weight.to(stage), num_nodes, improved,
+                          add_self_loops, flow, dtype)
+        return (edge_index if not add_self_loops else ei.to(home)), ew.to(home)
     num_nodes = maybe_num_nodes(edge_index, num_nodes)
     if add_self_loops:
         if edge_weight is None:
@@ -225,7 +242,9 @@ def normalize_adj_tensor(adj: torch.Tensor, sparse: bool = False):
                   a small dense matrix product, not part of the accelerated path.
     """
     if sparse:
-        _require_cuda(adj, "normalize_adj_tensor")
+        stage = _staging_device(adj, "normalize_adj_tensor")
+        if stage is not None:
+            return normalize_adj_tensor(adj.to(stage), sparse=True).to(adj.device)
         st = SparseTensor.from_torch_sparse_coo_tensor(adj)
         out = normalize_adj_csr(st)
         row, col, val = out.coo()
@@ -244,7 +263,9 @@ def normalize_sparse_tensor(adj: torch.Tensor, fill_value=1):
     edge order in float32 like the serial CPU scatter_add --, ``deg^-1/2`` with inf -> 0, and
     ``(deg_inv_sqrt[row] * w) * deg_inv_sqrt[col]`` left to right.  Returns an (uncoalesced) torch sparse COO tensor like
     the reference.  Same kernels as ``gcn_norm`` (degree by row = ``flow="target_to_source"``)."""
-    _require_cuda(adj, "normalize_sparse_tensor")
+    stage = _staging_device(adj, "normalize_sparse_tensor")
+    if stage is not None:
+        return normalize_sparse_tensor(adj.to(stage), fill_value).to(adj.device)
     edge_index, edge_weight = add_self_loops(adj._indices(), adj._values(), fill_value, adj.size(0))
     edge_index, values = gcn_norm(edge_index, edge_weight, adj.size(0), add_self_loops=False, flow="target_to_source")
     return torch.sparse_coo_tensor(edge_index, values, adj.shape)
