@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, NV == 1 ? (TAIL ? DISCO_WIN_WAVES - 1 : DISCO_
     for (int v = 0; v < NV; ++v) {
       int idx = gl + G * v;
       vinit<VEC, OP>(yv[v]);
-      if (resume && idx < nvec) {
+      if (resume && idx < nvec && !DISCO_WIN_YLATE) {
         if constexpr (DISCO_WIN_YLOAD != 0) yv[v] = __builtin_nontemporal_load(reinterpret_cast<const V*>(yr + (int64_t)idx * VEC));
         else yv[v] = *reinterpret_cast<const V*>(yr + (int64_t)idx * VEC);
       }
@@ -285,6 +285,11 @@ __global__ __launch_bounds__(256, NV == 1 ? (TAIL ? DISCO_WIN_WAVES - 1 : DISCO_
           int idx = gl + G * v;
           if (idx < nvec) {
             V a = acc[v];
+            if constexpr (DISCO_WIN_YLATE != 0) {
+              // the running sum is read AFTER this window's gathers (vector loads return in issue order: a memory-latency
+              // load at the head of a visit holds back the L2-hit gathers behind it) and this window's sum is added to it
+              if (resume) vcombine<VEC, OP>(a, *reinterpret_cast<const V*>(yr + (int64_t)idx * VEC));
+            }
             if (cnt > 0.0f) a = vdiv<VEC>(a, cnt);
             if (empty_row) a = 0.0f;
 #if defined(DISCO_DBG_NORMW)

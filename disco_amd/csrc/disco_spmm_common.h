@@ -57,6 +57,11 @@ template <> struct Vec<4> { typedef f4 type; };
 #ifndef DISCO_CSR_NT
 #define DISCO_CSR_NT 0
 #endif
+// 1: the windowed kernel starts every visit from zero and adds the running sum from y at the END of the visit
+// (y_new = y_old + sum of this window's entries: another association than the plain kernel's single CSR-order chain)
+#ifndef DISCO_WIN_YLATE
+#define DISCO_WIN_YLATE 0
+#endif
 
 template <class T> __device__ __forceinline__ T ld_entries(const T* p) {
   if constexpr (DISCO_CSR_NT != 0) return __builtin_nontemporal_load(p); else return *p;
