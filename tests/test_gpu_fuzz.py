@@ -625,3 +625,49 @@ def test_wrong_output_buffers_are_refused_before_any_launch():
     e1 = m.edges_from_scores(S, 0.5)
     e2 = m.edges_from_scores(S.t().contiguous().t(), 0.5)          # column-major view of the same matrix: copied, same edges
     assert torch.equal(e1[0], e2[0]) and torch.equal(e1[1], e2[1])
+
+
+def test_results_do_not_change_from_run_to_run():
+    """No atomics on any float: the same call gives the same bits every time -- plain, hub, windowed and K-hop propagation,
+    the normalisations, and the fused edge construction (whose edges leave the kernel in arrival order and are sorted)."""
+    from disco_amd import SparseTensor, ops, utils
+    from disco_amd.models.parametrized_adj_lp import PGE_Edge
+    n, F = 20000, 200
+    rowptr, col, val = random_csr(n, n, 40, seed=77, hubs=[(5, 9000), (77, 3000)], weighted=True, dup=False)
+    x = torch.from_numpy(np.random.default_rng(7).standard_normal((n, F)).astype(np.float32)).to(DEV)
+
+    def adj(window):
+        a = SparseTensor(rowptr=torch.from_numpy(rowptr).to(DEV), col=torch.from_numpy(col).to(DEV), value=torch.from_numpy(val).to(DEV),
+                         sparse_sizes=(n, n), is_sorted=True)
+        a.schedule(2048, 1024, feat=F, sweep=window, window_bytes=1 << 20)
+        return a
+
+    side = torch.cuda.Stream()
+    for window in (False, True):
+        for reduce in ("sum", "mean", "max"):
+            first = ops.spmm_raw(adj(window), x, reduce)
+            for _ in range(3):
+                assert torch.equal(ops.spmm_raw(adj(window), x, reduce), first), (window, reduce)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                other = ops.spmm_raw(adj(window), x, reduce)
+            side.synchronize()
+            assert torch.equal(other, first), (window, reduce, "another stream")
+    a = adj(False)
+    k1 = ops.khop(a, x, 3)
+    assert torch.equal(ops.khop(a, x, 3), k1)
+    ei = torch.from_numpy(np.random.default_rng(8).integers(0, n, (2, 300000))).to(DEV)
+    w = torch.rand(300000, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) + 0.1
+    g1 = utils.gcn_norm(ei, w, n)
+    g2 = utils.gcn_norm(ei, w, n)
+    assert torch.equal(g1[0], g2[0]) and torch.equal(g1[1], g2[1])
+    pos = a.set_value(a.storage.value().abs() + 0.1)              # negative row sums give NaN weights, as in the reference
+    n1 = utils.normalize_adj_csr(pos)
+    assert torch.equal(utils.normalize_adj_csr(pos).storage.value(), n1.storage.value()) and bool(torch.isfinite(n1.storage.value()).all())
+    torch.manual_seed(0)
+    m = PGE_Edge(nfeat=24, nhid=128, nlayers=3).to(DEV)
+    Z = torch.randn(1500, 24, device=DEV)
+    e1 = m.edge_construction(Z, 0.5)
+    for _ in range(3):
+        e2 = m.edge_construction(Z, 0.5)
+        assert torch.equal(e1[0], e2[0]) and torch.equal(e1[1], e2[1])
