@@ -16,6 +16,7 @@ from __future__ import annotations
 from typing import Optional, Tuple
 
 import math
+import weakref
 
 import torch
 
@@ -158,10 +159,10 @@ class SparseTensor:
         self._window_bytes: Optional[int] = None   # sticky schedule(window_bytes=) override
         self._hub_ws: Optional[torch.Tensor] = None    # partial-row workspace of the hub kernels (grown on demand)
         self._row_groups: Optional[torch.Tensor] = None   # locality groups: major key of the row order
-        self._t: Optional["SparseTensor"] = None
+        self._t: Optional["SparseTensor"] = None      # the transposed matrix once built (strong: it is derived from this one)
+        self._t_of = None                              # weakref to the matrix this one was transposed FROM (see t())
         self._on_device = {}        # host-resident object: its device copies, one per GPU (see to())
         self._shared = _StructCache()
-        self.storage = _Storage(self)
 
     @classmethod
     def _from_parts(cls, rowptr: torch.Tensor, col32: torch.Tensor, value: Optional[torch.Tensor],
@@ -201,6 +202,13 @@ class SparseTensor:
                    sparse_sizes=mat.shape, is_sorted=True)
 
     # ---- accessors --------------------------------------------------------------------------
+    @property
+    def storage(self) -> _Storage:
+        """``adj.storage`` facade, made on demand: an attribute pointing back at its owner would be a reference cycle, and a
+        SparseTensor in a cycle keeps its device arrays until Python's cycle collector runs (every ``set_value`` copy a
+        propagation makes would linger)."""
+        return _Storage(self)
+
     @property
     def device(self) -> torch.device:
         return self._col32.device
@@ -297,6 +305,10 @@ class SparseTensor:
         """Transposed matrix as CSR (row-major sorted, stable in the original entry order).  The transposed
         structure and the value permutation are built once per structure and shared by ``set_value`` copies
         (the backward of every training step on the condensed graph re-uses them)."""
+        if self._t is None and self._t_of is not None:
+            origin = self._t_of()
+            if origin is not None:
+                return origin
         if self._t is None:
             sh = self._shared
             if sh.t_struct is None:
@@ -316,7 +328,10 @@ class SparseTensor:
                     c32 = row[perm].to(torch.int32)
                 sh.t_struct, sh.t_perm = SparseTensor._from_parts(rp, c32.contiguous(), None, sizes_t), perm
             out = sh.t_struct.set_value(None if self._value is None else torch.index_select(self._value, 0, sh.t_perm))
-            out._t = self
+            # a.t().t() is a -- but through a WEAK back-pointer: the reference writes `SparseTensor(...).t()` and drops the
+            # untransposed object at once (LargeScaleCondensing.py:486); a strong pair would be a reference cycle that keeps
+            # both CSR copies (2 x 13.8 GB at papers100M size) alive until Python's cycle collector happens to run
+            out._t_of = weakref.ref(self)
             self._t = out
         return self._t
 

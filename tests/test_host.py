@@ -420,3 +420,31 @@ def test_sparse_tensor_host_construction_properties():
         assert r2.tolist() == row[order].tolist() and c2.tolist() == col[order].tolist()
 
     check()
+
+
+def test_sparse_tensors_are_freed_by_reference_counting_alone():
+    """No reference cycles: dropping the last name of a SparseTensor (or of the untransposed half of `SparseTensor(...).t()`,
+    the reference's idiom) frees it at once, with the cycle collector switched off -- on the GPU that is 13.8 GB per copy at
+    papers100M size."""
+    import gc
+    import weakref
+    gc.collect()
+    gc.disable()
+    try:
+        a = SparseTensor(row=torch.tensor([0, 1, 2, 2]), col=torch.tensor([1, 0, 0, 2]), value=torch.arange(4.0), sparse_sizes=(3, 3))
+        wa = weakref.ref(a)
+        t = a.t()
+        assert t.t() is a and a.t() is t and a.storage.value() is a._value
+        b = a.set_value(torch.ones(4))
+        wb = weakref.ref(b)
+        del b
+        assert wb() is None, "a set_value copy survived its last reference"
+        del a
+        assert wa() is None, "the untransposed matrix survived `SparseTensor(...).t()`"
+        assert t.t().t() is t                                   # the origin is gone: transposing again builds a new pair
+        assert torch.equal(t.t().to_dense(), t.to_dense().t())
+        wt = weakref.ref(t)
+        del t
+        assert wt() is None
+    finally:
+        gc.enable()
