@@ -41,6 +41,14 @@ def _worker(rank, port, result_dir):
         assert work is not None
         work.wait()
         assert torch.equal(out, inp)
+        # a rank that neither sends nor receives anything (halo-free block): empty buffers, zero splits
+        e_in, e_out = torch.empty(0, device=dev), torch.empty(0, device=dev)
+        work = dd._all_to_all(e_out, e_in, [0], [0], async_op=True)
+        if work is not None:
+            work.wait()
+        cnt_in, cnt_out = torch.tensor([5], dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+        dd._all_to_all(cnt_out, cnt_in)                      # the int64 count exchange of RowPartition.__init__
+        assert int(cnt_out) == 5
         full = torch.empty(24, device=dev)
         work = dd._all_gather_into(full, torch.arange(24, dtype=torch.float32, device=dev), async_op=True)
         work.wait()
