@@ -276,3 +276,46 @@ def test_launches_beyond_two_to_the_32_work_items():
         bad += int((out[i:i + big] != dis[row[i:i + big]] * dis[colE[i:i + big]]).sum())
     assert bad == 0, f"{bad} of {E} weights wrong or never written"
     _progress("[wrap] done")
+
+
+def test_coo_to_csr_beyond_two_to_the_31_entries():
+    """disco_coo_to_csr with more than 2^31 entries (ogbn-papers100M symmetrised is 3.2 G): 2.2 G distinct cells of a 65 536 x
+    65 536 grid in scrambled order; the result must hold every entry once, rows ascending, columns strictly ascending inside a
+    row, and the same sum of cell ids (with distinct, strictly ordered cells that pins the set)."""
+    from disco_amd.sparse import coo_to_csr
+    dev = torch.device(DEV)
+    E, side = 2_200_000_000, 1 << 16
+    _progress(f"[sort] building {E} entries")
+    row = torch.empty(E, dtype=torch.int64, device=dev)
+    col = torch.empty(E, dtype=torch.int64, device=dev)
+    big = 1 << 27
+    s_sum = torch.zeros((), dtype=torch.int64, device=dev)
+    for i in range(0, E, big):
+        c = torch.arange(i, min(i + big, E), device=dev)
+        cell = (c * 2_654_435_761) & 0xffffffff               # odd multiplier: a bijection of [0, 2^32)
+        row[i:i + big] = cell >> 16
+        col[i:i + big] = cell & 0xffff
+        s_sum += cell.sum()
+    del c, cell
+    _progress("[sort] coo_to_csr")
+    rowptr, c32, _ = coo_to_csr(row, col, None, (side, side), dup="keep", want_value=False)
+    del row, col
+    torch.cuda.synchronize()
+    _progress("[sort] checking")
+    assert c32.numel() == E and int(rowptr[-1]) == E and int(rowptr[0]) == 0
+    assert bool((rowptr[1:] >= rowptr[:-1]).all())
+    got_sum = torch.zeros((), dtype=torch.int64, device=dev)
+    bad = 0
+    for i in range(0, E, big):
+        j = min(i + big, E)
+        cc = c32[i:j].to(torch.int64)
+        pos = torch.arange(i, j, device=dev)
+        rr = torch.searchsorted(rowptr, pos, right=True) - 1
+        got_sum += (rr * side + cc).sum()
+        # strictly ascending inside a row: compare with the previous entry unless this entry opens its row
+        prev = c32[max(i - 1, 0):j - 1].to(torch.int64) if i > 0 else torch.cat([cc.new_full((1,), -1), cc[:-1]])
+        opens = rowptr[rr] == pos
+        bad += int(((cc <= prev) & ~opens).sum())
+    assert bad == 0, f"{bad} entries out of order"
+    assert int(got_sum) == int(s_sum), "the multiset of cells changed"
+    _progress("[sort] done")
