@@ -24,10 +24,10 @@ def assert_fwd_close(y, y64, bound, rtol=RTOL, what="", rel_floor=REL_FLOOR):
     y64 = np.asarray(y64, dtype=np.float64)
     err = np.abs(y - y64)
     lim = rtol * bound + 1e-37
-    bad = err > lim
+    bad = ~(err <= lim)                    # NaN / inf in y compare false with everything: they must count as failures
     assert not bad.any(), f"{what}: {bad.sum()} elements exceed {rtol} * sum|w x| (worst ratio {np.max(err / np.maximum(bound, 1e-300)):.3e})"
     big = (np.abs(y64) >= rel_floor * bound) & (bound > 0)
-    bad_rel = big & (err > rtol * np.abs(y64) + 1e-37)
+    bad_rel = big & ~(err <= rtol * np.abs(y64) + 1e-37)
     assert not bad_rel.any(), (f"{what}: {bad_rel.sum()} of {big.sum()} non-cancelling elements exceed the element-relative "
                                f"{rtol} (worst {np.max(err[big] / np.abs(y64[big])):.3e})")
 

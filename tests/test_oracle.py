@@ -279,3 +279,20 @@ def test_normalize_sparse_tensor_restatement_matches_stock_torch():
     assert np.array_equal(r, ei[0].numpy()) and np.array_equal(c, ei[1].numpy())
     ulp = np.abs(v.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)).max()
     assert ulp <= 2, ulp
+
+
+def test_tolerance_helper_counts_nan_and_inf_as_failures():
+    """A result holding NaN or inf compares false with every bound: the checker must fail on it, not pass vacuously."""
+    from helpers import assert_fwd_close
+    y64 = np.ones((4, 3))
+    bound = np.full((4, 3), 2.0)
+    assert_fwd_close(y64.astype(np.float32), y64, bound)
+    for poison in (np.nan, np.inf, -np.inf):
+        y = y64.astype(np.float32).copy()
+        y[2, 1] = poison
+        with pytest.raises(AssertionError):
+            assert_fwd_close(y, y64, bound)
+    y = y64.astype(np.float32).copy()
+    y[0, 0] += 1e-3
+    with pytest.raises(AssertionError):
+        assert_fwd_close(y, y64, bound)
