@@ -671,3 +671,66 @@ def test_results_do_not_change_from_run_to_run():
     for _ in range(3):
         e2 = m.edge_construction(Z, 0.5)
         assert torch.equal(e1[0], e2[0]) and torch.equal(e1[1], e2[1])
+
+
+@pytest.mark.parametrize("case", list(range(16)))
+def test_random_misaligned_views_through_the_c_abi(case):
+    """Operands that are column views starting 4, 8 or 12 bytes into a wider buffer (x, y or both), any leading dimension:
+    the C entry point must fall back to the widest vector the pointers AND pitches allow, write nothing outside the view,
+    and give the oracle's result -- for the plain, scheduled and windowed paths and K-hop scratch buffers alike."""
+    from disco_amd import SparseTensor, _lib, ops
+    rng = np.random.default_rng(8000 + case)
+    n = int(rng.choice([50, 700, 3000]))
+    F = int(rng.choice([1, 4, 31, 64, 100, 130, 256]))
+    xoff, yoff = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+    ldx = F + xoff + int(rng.choice([0, 1, 3, 4, 28]))
+    ldy = F + yoff + int(rng.choice([0, 1, 3, 4, 28]))
+    reduce = str(rng.choice(["sum", "mean", "max", "sum_acc"]))
+    hubs = [(int(rng.integers(0, n)), 3000)] if n >= 700 and rng.random() < 0.5 else []
+    rowptr, col, val = random_csr(n, n, float(rng.choice([3, 40])), seed=8000 + case, hubs=hubs, weighted=True, dup=False)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    y0 = rng.standard_normal((n, F)).astype(np.float32)
+    xb = torch.full((n, ldx), 9.0, device=DEV)
+    xb[:, xoff:xoff + F] = torch.from_numpy(x).to(DEV)
+    yb = torch.full((n, ldy), 7.0, device=DEV)
+    yv = yb[:, yoff:yoff + F]
+    yv.copy_(torch.from_numpy(y0).to(DEV) if reduce == "sum_acc" else torch.zeros(n, F, device=DEV))
+    adj = SparseTensor(rowptr=torch.from_numpy(rowptr).to(DEV), col=torch.from_numpy(col).to(DEV),
+                       value=None if reduce == "max" else torch.from_numpy(val).to(DEV), sparse_sizes=(n, n), is_sorted=True)
+    lib = _lib.load()
+    window = bool(rng.random() < 0.4)
+    use_sched = bool(rng.random() < 0.7)
+    ws_ptr = info = sws = None
+    sws_bytes = 0
+    if use_sched:
+        ws, info = adj.schedule(2048, 1024, feat=F, sweep=window, window_bytes=64 * 4 * min(128, (F + 31) // 32 * 32))
+        ws_ptr = _lib.ptr(ws)
+        nb = int(lib.disco_spmm_workspace_bytes(info, F))
+        if nb:
+            sws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+            sws_bytes = nb
+    xv = xb[:, xoff:xoff + F]
+    code = {"sum": 0, "mean": 1, "max": 2, "sum_acc": 3}[reduce]
+    _lib.check(lib.disco_spmm_csr_f32(_lib.ptr(adj._rowptr), _lib.ptr(adj._col32), _lib.ptr(adj._value), n, xv.data_ptr(), ldx,
+                                      yv.data_ptr(), ldy, F, code, ws_ptr, info, _lib.ptr(sws), sws_bytes, _lib.current_stream(torch.device(DEV))),
+               "disco_spmm_csr_f32")
+    torch.cuda.synchronize()
+    got = yb.cpu().numpy()
+    mask = np.ones((n, ldy), dtype=bool)
+    mask[:, yoff:yoff + F] = False
+    what = dict(case=case, n=n, F=F, xoff=xoff, yoff=yoff, ldx=ldx, ldy=ldy, reduce=reduce, sched=use_sched, window=window)
+    assert (got[mask] == 7.0).all(), f"{what}: wrote outside the view"
+    assert bool((xb[:, :xoff] == 9.0).all()) and bool((xb[:, xoff + F:] == 9.0).all())
+    y = got[:, yoff:yoff + F]
+    if reduce == "max":
+        assert np.array_equal(y, c_oracle.spmm_csr_f32(rowptr, col, None, x, "max")), str(what)
+    else:
+        y64, bound = c_oracle.spmm_csr_f64acc(rowptr, col, val, x, want_bound=True)
+        if reduce == "mean":
+            cnt = np.maximum(np.diff(rowptr), 1)[:, None].astype(np.float64)
+            y64, bound = y64 / cnt, bound / cnt
+        if reduce == "sum_acc":
+            y64, bound = y64 + y0.astype(np.float64), bound + np.abs(y0)
+        long_seq = (not use_sched) & (np.diff(rowptr) > 2048)
+        assert_fwd_close(y[~long_seq], y64[~long_seq], bound[~long_seq], what=str(what))
+        assert_fwd_close(y[long_seq], y64[long_seq], bound[long_seq], what=str(what), rel_floor=np.inf)
